@@ -1,0 +1,151 @@
+/* lq_hip.h -- C ABI of the MI355X (gfx950) learned-quantization hot path.
+ *
+ * The reference (anuunchin/learned-quantization) is pure Python on TensorFlow 2.11
+ * and has no native interface of its own; the operator surface it exposes for this
+ * path is the Python op `my_custom_gradient` and the loss-term methods.  Every entry
+ * point below names the reference interface it replaces (file:line relative to
+ * /root/reference).  The ctypes binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes, no framework types; all tensor pointers are DEVICE
+ *     pointers to contiguous float32 unless stated otherwise;
+ *   - group descriptor (outer, G, inner): element i of a contiguous tensor uses scale
+ *     element  g = (i / inner) % G ; numel = outer * G * inner.  It encodes the four
+ *     `orientation`s of CustomQuantizedScaleLayer.build
+ *     (MNIST/nested_quantization_layer/custom_components/custom_layers.py:147-197);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); kernels are
+ *     enqueued and the call returns without synchronising; nothing is allocated;
+ *   - `ws` is caller-owned DEVICE scratch of at least lq_workspace_bytes(outer,G,inner)
+ *     bytes, 16-byte aligned; it carries deterministic two-stage reduction partials
+ *     (no float atomics: results are run-to-run bit-stable);
+ *   - return value: LQ_OK (0) or a negative lq_status; lq_last_error() returns a
+ *     thread-local message for the last failing call on this thread.
+ */
+#ifndef LQ_HIP_H_
+#define LQ_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LQ_ABI_VERSION 1
+
+typedef enum lq_status {
+    LQ_OK = 0,
+    LQ_EINVAL = -1,      /* bad argument (null pointer, non-positive extent, bad enum) */
+    LQ_EHIP = -2,        /* a HIP runtime call / kernel launch failed                  */
+    LQ_EWORKSPACE = -3,  /* workspace missing or too small                             */
+    LQ_EALIGN = -4       /* pointer not 4-byte aligned / workspace not 16-byte aligned */
+} lq_status;
+
+typedef enum lq_qdtype {
+    LQ_Q_NONE = 0,
+    LQ_Q_F32 = 1,        /* integer-valued float32, exactly the reference's tf.floor output */
+    LQ_Q_I32 = 2,        /* saturating float->int32                                          */
+    LQ_Q_I8 = 3          /* two's-complement wrap of the integer, = numpy .astype(int8) of
+                            CIFAR-10/nested_quantization_layer/utils/log_scripts.py:74-79    */
+} lq_qdtype;
+
+typedef enum lq_adam_mode {
+    LQ_ADAM_KERAS = 0,   /* Keras 2.11: var -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps) */
+    LQ_ADAM_TORCH = 1    /* torch.optim.Adam: m_hat / (sqrt(v_hat) + eps)                      */
+} lq_adam_mode;
+
+int lq_version(void);                 /* LQ_ABI_VERSION of the loaded library            */
+const char* lq_last_error(void);      /* thread-local, never NULL                        */
+const char* lq_status_string(int status);
+
+/* Scratch bytes needed by every reducing entry point for this descriptor. */
+size_t lq_workspace_bytes(int64_t outer, int64_t G, int64_t inner);
+
+/* ---- K1: fake-quant forward -------------------------------------------------------
+ * Replaces the forward of `my_custom_gradient`
+ *   MNIST/nested_quantization_layer/custom_components/custom_layers.py:55-60,120
+ *   CIFAR-10/custom_loss_terms/custom_components/custom_layers.py:53-59,64
+ * t = P / s (IEEE RN), q = floor(t), out = q * s.  `out` may be NULL when only q is
+ * wanted (callbacks/export: custom_callbacks.py:85-87, log_scripts.py:74-79).       */
+int lq_fq_forward(const float* P, const float* s, float* out, void* q, int q_dtype,
+                  int64_t outer, int64_t G, int64_t inner, void* stream);
+
+/* ---- K2+K3: nested-quantization scale gradient ------------------------------------
+ * Replaces `custom_grad` of the NQ op, custom_layers.py:62-118:
+ *   ratio = |dy| / |where(out==0, eps_f32, out)|            (:63-64)
+ *   m_g = max|q| , A_g = all(ratio >= lambda)                (:68-73, :94-99)
+ *   mean_g = A_g ? -|tanh(lambda)| : mean(ratio>=lambda ? 0 : -|tanh(lambda-ratio)|)  (:77-88,:103-114)
+ *   ds[g] = mean_g * m_g                                     (:116)
+ * dP is `dy` itself (STE, :118) and is therefore not an output.
+ * `parts` (optional, DEVICE float[3*G]) receives m_g, mean_g and the count of elements
+ * with ratio < lambda (as float) for diagnostics / tests.                             */
+int lq_fq_scale_grad(const float* P, const float* s, const float* dy, float lambda,
+                     float* ds, float* parts, void* ws, size_t ws_bytes,
+                     int64_t outer, int64_t G, int64_t inner, void* stream);
+
+/* ---- K4: forward and NQ backward of one tensor in a single pass (benchmark path) ---
+ * Same results as lq_fq_forward followed by lq_fq_scale_grad; P is read once.        */
+int lq_fq_fwd_bwd_fused(const float* P, const float* s, const float* dy, float lambda,
+                        float* out, float* ds, void* ws, size_t ws_bytes,
+                        int64_t outer, int64_t G, int64_t inner, void* stream);
+
+/* ---- K5a: MaxBin penalty tensor term ------------------------------------------------
+ * Replaces the per-tensor part of SCCEMaxBin.compute_maxbin_penalty,
+ *   CIFAR-10/custom_loss_terms/custom_components/custom_loss_functions.py:90-100,110:
+ *   mb[g] = max_{i in g} |P_i| / s[g] ;  *term = mean_g mb[g].
+ * `ties[g]` = number of elements attaining the maximum (TensorFlow's reduce_max gradient
+ * splits evenly over ties).  Backward for upstream c = (*c_dev) * c_scale on `term`:
+ *   dP_i = (|P_i|/s == mb[g]) ? sign(P_i) * c / (G * ties[g] * s[g]) : 0
+ *   ds[g] = -c * mb[g] / (G * s[g])                                                   */
+int lq_penalty_maxbin_fwd(const float* P, const float* s, float* mb, uint32_t* ties, float* term,
+                          void* ws, size_t ws_bytes,
+                          int64_t outer, int64_t G, int64_t inner, void* stream);
+int lq_penalty_maxbin_bwd(const float* P, const float* s, const float* mb, const uint32_t* ties,
+                          const float* c_dev, float c_scale, float* dP, float* ds,
+                          int64_t outer, int64_t G, int64_t inner, void* stream);
+
+/* ---- K5b: Difference penalty tensor term --------------------------------------------
+ * Replaces the per-tensor part of SCCEDifference.compute_difference_penalty,
+ *   custom_loss_functions.py:172-176:  *term = mean_i |P_i - P_i / s[g]|.
+ * Backward, u = P - P/s, gi = sign(u) * c / N:
+ *   dP_i = gi - gi / s[g] ;  ds[g] = sum_{i in g} gi * (P_i / s[g]) / s[g]           */
+int lq_penalty_difference_fwd(const float* P, const float* s, float* term,
+                              void* ws, size_t ws_bytes,
+                              int64_t outer, int64_t G, int64_t inner, void* stream);
+int lq_penalty_difference_bwd(const float* P, const float* s, const float* c_dev, float c_scale,
+                              float* dP, float* ds, void* ws, size_t ws_bytes,
+                              int64_t outer, int64_t G, int64_t inner, void* stream);
+
+/* ---- K5c: Inverse penalty tensor term -----------------------------------------------
+ * Replaces the per-tensor part of SCCEInverse.compute_inverse_penalty,
+ *   custom_loss_functions.py:252-256:  *term = mean_g 1 / where(s[g]==0, eps_f32, s[g]).
+ * Backward: ds[g] = s[g]==0 ? 0 : -c / (G * s[g]^2).                                  */
+int lq_penalty_inverse_fwd(const float* s, float* term, int64_t G, void* stream);
+int lq_penalty_inverse_bwd(const float* s, const float* c_dev, float c_scale, float* ds,
+                           int64_t G, void* stream);
+
+/* ---- K6: scale update ---------------------------------------------------------------
+ * Adam step on a scale vector fused with the projection of MinValueConstraint
+ *   custom_layers.py:35-46, attached at :158,170,182,191 with min_value = 100*eps_f32:
+ *   s <- max(adam(s, ds), min_value).  `step` is the 1-based iteration count.
+ * lq_min_value_project is the bare constraint  w <- max(w, min_value)  (:42-43).      */
+int lq_scale_adam_step(float* s, const float* ds, float* m, float* v, int64_t n,
+                       float lr, float beta1, float beta2, float eps, int64_t step,
+                       float min_value, int mode, void* stream);
+int lq_min_value_project(float* w, int64_t n, float min_value, void* stream);
+
+/* ---- integer-view statistics (callbacks) ----------------------------------------------
+ * max |floor(P/s)| over all elements sharing the index along `axis` of a tensor viewed
+ * as (pre, n_axis, post) -- the reduce_max(abs(q), axis=1) of
+ *   CIFAR-10/nested_quantization_layer/custom_components/custom_callbacks.py:98-99
+ * is the complementary reduction: it keeps every axis but 1.  Here `keep_pre`/`keep_post`
+ * select the kept extents: result[pre_i, post_j] = max over the middle axis.
+ * The scale descriptor (outer,G,inner) is independent of the reduction geometry.      */
+int lq_q_absmax_over_axis(const float* P, const float* s, float* result,
+                          int64_t pre, int64_t n_axis, int64_t post,
+                          int64_t outer, int64_t G, int64_t inner, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LQ_HIP_H_ */

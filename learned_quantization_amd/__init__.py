@@ -1,0 +1,18 @@
+"""learned_quantization_amd -- MI355X-native (gfx950) learned-quantization hot path.
+
+The nested-quantization fake-quant op (forward, STE, hand-written scale gradient), the three
+custom loss terms and the scale update of anuunchin/learned-quantization, behind the
+reference's own Python layer surface, executed by hand-written HIP kernels through the C ABI of
+``include/lq_hip.h``.  See DESIGN.md / INTEGRATION.md.
+"""
+from .descriptor import ORIENTATIONS, group_descriptor, scale_shape
+from .layers import (CustomConv2DLayer, CustomConv2DLayerNoBias, CustomDenseLayer, CustomQuantizedScaleLayer,
+                     L2, MinValueConstraint, RandomNormal, SCALE_INIT, custom_layers_of, eps_float32, l2,
+                     reset_layer_names)
+from .losses import SCCEDifference, SCCEInverse, SCCEMaxBin, sparse_categorical_crossentropy
+from .ops import (difference_term, fq_forward, fq_fwd_bwd_fused, fq_scale_grad, inverse_term, maxbin_term,
+                  my_custom_gradient, q_absmax_over_axis, quantized_integers)
+from .optim import ScaleAdam, apply_constraints, non_scale_parameters, scale_parameters
+from .ddp import DataParallel, GradBucket
+
+__version__ = "0.1.0"

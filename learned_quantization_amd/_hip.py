@@ -1,0 +1,127 @@
+"""ctypes binding of liblq_hip.so (the C ABI of include/lq_hip.h).
+
+There is NO fallback: if the HIP library is missing, or a tensor is not a
+contiguous float32 tensor on a HIP device, the call raises.  PyTorch is used
+only for device memory and streams (``tensor.data_ptr()``,
+``torch.cuda.current_stream().cuda_stream``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Dict, Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblq_hip.so")
+
+LQ_Q_NONE, LQ_Q_F32, LQ_Q_I32, LQ_Q_I8 = 0, 1, 2, 3
+LQ_ADAM_KERAS, LQ_ADAM_TORCH = 0, 1
+
+_c_i64 = ctypes.c_int64
+_c_f = ctypes.c_float
+_c_p = ctypes.c_void_p
+_c_sz = ctypes.c_size_t
+_c_int = ctypes.c_int
+
+#: name -> (restype, argtypes); one entry per symbol declared in include/lq_hip.h
+SIGNATURES = {
+    "lq_version": (_c_int, []),
+    "lq_last_error": (ctypes.c_char_p, []),
+    "lq_status_string": (ctypes.c_char_p, [_c_int]),
+    "lq_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "lq_fq_forward": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_int, _c_i64, _c_i64, _c_i64, _c_p]),
+    "lq_fq_scale_grad": (_c_int, [_c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p, _c_sz, _c_i64, _c_i64, _c_i64, _c_p]),
+    "lq_fq_fwd_bwd_fused": (_c_int, [_c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p, _c_sz, _c_i64, _c_i64, _c_i64, _c_p]),
+    "lq_penalty_maxbin_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_sz, _c_i64, _c_i64, _c_i64, _c_p]),
+    "lq_penalty_maxbin_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
+    "lq_penalty_difference_fwd": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_sz, _c_i64, _c_i64, _c_i64, _c_p]),
+    "lq_penalty_difference_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p, _c_sz, _c_i64, _c_i64, _c_i64, _c_p]),
+    "lq_penalty_inverse_fwd": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
+    "lq_penalty_inverse_bwd": (_c_int, [_c_p, _c_p, _c_f, _c_p, _c_i64, _c_p]),
+    "lq_scale_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_i64, _c_f, _c_int, _c_p]),
+    "lq_min_value_project": (_c_int, [_c_p, _c_i64, _c_f, _c_p]),
+    "lq_q_absmax_over_axis": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+_lock = threading.Lock()
+
+
+class LQError(RuntimeError):
+    """A C-ABI call returned a negative lq_status."""
+
+
+def load() -> ctypes.CDLL:
+    """Loads liblq_hip.so and binds every prototype.  Raises loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"learned_quantization_amd: HIP extension not built ({LIB_PATH} missing). "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C learned_quantization_amd/csrc`.  There is no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError here = ABI mismatch, also loud
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+        return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        msg = lib.lq_last_error().decode("utf-8", "replace")
+        raise LQError(f"{what} failed: {lib.lq_status_string(rc).decode()} ({rc}): {msg}")
+
+
+def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: the learned-quantization ops run only on a HIP device "
+            "(MI355X); there is no CPU fallback"
+        )
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> Optional[int]:
+    s = torch.cuda.current_stream(device).cuda_stream
+    return s if s else None
+
+
+# ------------------------------------------------------------------ workspace cache
+_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, stream); stream-ordered reuse is safe because
+    every consumer of the partials is enqueued on the same stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        nbytes = max(int(nbytes), 1 << 16)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def workspace_for(device: torch.device, outer: int, G: int, inner: int) -> torch.Tensor:
+    return workspace(device, load().lq_workspace_bytes(outer, G, inner))

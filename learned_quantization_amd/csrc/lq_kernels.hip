@@ -1,0 +1,1082 @@
+// lq_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels for the learned-quantization
+// hot path, and the C ABI of include/lq_hip.h on top of them.
+//
+// The path is elementwise + per-group reductions: HBM-bound, no MFMA.  Design rules
+// (cdna_hip_programming.md G2/G11/G12/G13, MI355X_MICROARCH.md HBM):
+//   * 16-byte-per-lane coalesced global loads/stores (float4) on every large tensor;
+//   * the per-group scale is wave/block-uniform in the streaming kernels (one scalar
+//     load, SGPR broadcast) -- the group index never costs per-element integer division;
+//   * reductions: DPP/shuffle inside the 64-lane wave -> LDS across the 4 waves of a
+//     block -> one partial per block in a workspace -> a finalize kernel.  No float
+//     atomics: every sum is taken in a fixed order, results are run-to-run bit-stable;
+//   * max|q| is reduced on the uint32 bit pattern of |q| (order-independent, exact,
+//     NaN-propagating like np.max);
+//   * the integers must match the reference bit for bit: IEEE-754 correctly rounded
+//     fp32 division followed by floor (never a reciprocal multiply), -ffp-contract=off,
+//     no fast-math.
+//
+// Reference semantics restated here (file:line relative to /root/reference):
+//   forward           MNIST/nested_quantization_layer/custom_components/custom_layers.py:55-60
+//   NQ backward       custom_layers.py:62-118
+//   penalties         CIFAR-10/custom_loss_terms/custom_components/custom_loss_functions.py:75-116,161-195,240-275
+//   constraint        custom_layers.py:35-46
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "lq_hip.h"
+
+namespace lq {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr float kEpsF32 = 1.1920928955078125e-07f;   // np.finfo(np.float32).eps, custom_layers.py:11
+constexpr int64_t kChunkMax = 8192;                  // elements per block in the streaming kernels
+constexpr int kUnroll = 4;                           // independent 16-B loads in flight per lane and operand
+
+// ------------------------------------------------------------------------------------------
+//  Parameters shared by every kernel (passed by value in the kernarg segment).
+// ------------------------------------------------------------------------------------------
+struct Params {
+    const float* P;
+    const float* s;
+    const float* dy;
+    float* out;          // primary dense output (out for K1/K4, dP for penalty backward)
+    void* q;             // optional integer view
+    int q_dtype;
+    float lam;
+    const float* mb;     // per-group max(|P|/s)      (maxbin backward)
+    const uint32_t* ties;
+    const float* c_dev;  // upstream gradient, device scalar
+    float c_scale;
+    uint32_t* pa;        // partials, SoA
+    uint32_t* pb;
+    float* pc;
+    int64_t outer, G, inner;
+};
+
+// Per-group context, loaded once per row / column.
+struct Ctx {
+    float s;
+    float k0;
+    float k1;
+};
+
+// Narrow accumulator (inside streaming kernels) and wide accumulator (finalize).
+template <typename TB, typename TC>
+struct AccT {
+    uint32_t a;
+    TB b;
+    TC c;
+};
+using Acc = AccT<uint32_t, float>;
+using AccW = AccT<unsigned long long, double>;
+
+enum OpKind {
+    OP_FWD = 0,        // K1
+    OP_BWD = 1,        // K2
+    OP_FUSED = 2,      // K4
+    OP_MAXBIN_FWD = 3, // K5a
+    OP_MAXBIN_BWD = 4,
+    OP_DIFF_FWD = 5,   // K5b
+    OP_DIFF_BWD = 6,
+    OP_QONLY = 7,      // integer view only (callbacks / export)
+};
+
+// |tanh(d)|.  For |d| < 4e-4, tanh(d) == d to fp32 precision (d^2/3 < 2^-24): the published
+// thresholds (lambda <= 1e-8) never leave this branch.  Otherwise ocml tanhf (<= 2 ulp).
+__device__ __forceinline__ float abs_tanh(float d) {
+    float a = fabsf(d);
+    if (a < 4.0e-4f) return a;
+    return tanhf(a);
+}
+
+__device__ __forceinline__ void fq_core(float x, float s, float& q, float& o) {
+    float t = x / s;      // IEEE RN fp32 division (hipcc default: correctly rounded) -- custom_layers.py:56-58
+    q = floorf(t);        // :59
+    o = q * s;            // :60
+}
+
+__device__ __forceinline__ void nq_accumulate(float q, float o, float dy, float lam, Acc& acc) {
+    float nz = (o == 0.0f) ? kEpsF32 : o;              // :63
+    float ratio = fabsf(dy) / fabsf(nz);               // :64
+    uint32_t aq = __float_as_uint(fabsf(q));           // :68 / :94  max|q| on the bit pattern
+    acc.a = aq > acc.a ? aq : acc.a;
+    if (!(ratio >= lam)) {                             // :70 / :97 (NaN counts as "not above")
+        acc.b += 1u;
+        acc.c += -abs_tanh(lam - ratio);               // :84 / :110
+    }
+}
+
+template <int Q>
+__device__ __forceinline__ void store_q_scalar(void* qp, int64_t i, float q) {
+    if (Q == LQ_Q_F32) {
+        reinterpret_cast<float*>(qp)[i] = q;
+    } else if (Q == LQ_Q_I32) {
+        reinterpret_cast<int32_t*>(qp)[i] = (q != q) ? 0 : (q >= 2147483648.0f ? INT32_MAX : (q <= -2147483648.0f ? INT32_MIN : (int32_t)q));
+    } else if (Q == LQ_Q_I8) {
+        // two's-complement wrap of the (finite) integer value: what a C cast chain float->int64->int8 gives
+        long long w = (q != q || fabsf(q) > 9.0e18f) ? 0ll : (long long)q;
+        reinterpret_cast<int8_t*>(qp)[i] = (int8_t)(uint8_t)(w & 0xff);
+    }
+}
+
+__device__ __forceinline__ void store_q(void* qp, int q_dtype, int64_t i, float q) {
+    switch (q_dtype) {
+        case LQ_Q_F32: store_q_scalar<LQ_Q_F32>(qp, i, q); break;
+        case LQ_Q_I32: store_q_scalar<LQ_Q_I32>(qp, i, q); break;
+        case LQ_Q_I8: store_q_scalar<LQ_Q_I8>(qp, i, q); break;
+        default: break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Op traits.  elem() consumes one element (x, dy) of group context c at flat index i, returns
+//  the value of the primary dense output (stored, vectorised, by the traversal when kStore)
+//  and folds into acc when kReduce.
+// ------------------------------------------------------------------------------------------
+template <int OP>
+struct OpT;
+
+struct OpBase {
+    static constexpr bool kDy = false;
+    static constexpr bool kStore = false;
+    static constexpr bool kReduce = false;
+    template <typename A>
+    __device__ static __forceinline__ A init() {
+        A a;
+        a.a = 0u;
+        a.b = 0;
+        a.c = 0;
+        return a;
+    }
+    template <typename A, typename B>
+    __device__ static __forceinline__ void merge(A& x, const B& y) {
+        x.a = y.a > x.a ? y.a : x.a;
+        x.b += y.b;
+        x.c += y.c;
+    }
+    __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) {
+        Ctx c;
+        c.s = p.s[g];
+        c.k0 = 0.f;
+        c.k1 = 0.f;
+        return c;
+    }
+};
+
+template <>
+struct OpT<OP_FWD> : OpBase {
+    static constexpr bool kStore = true;
+    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float, Acc&) {
+        float q, o;
+        fq_core(x, c.s, q, o);
+        if (p.q) store_q(p.q, p.q_dtype, i, q);
+        return o;
+    }
+};
+
+template <>
+struct OpT<OP_QONLY> : OpBase {
+    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float, Acc&) {
+        float q, o;
+        fq_core(x, c.s, q, o);
+        store_q(p.q, p.q_dtype, i, q);
+        return 0.f;
+    }
+};
+
+template <>
+struct OpT<OP_BWD> : OpBase {
+    static constexpr bool kDy = true;
+    static constexpr bool kReduce = true;
+    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t, float x, float dy, Acc& acc) {
+        float q, o;
+        fq_core(x, c.s, q, o);
+        nq_accumulate(q, o, dy, p.lam, acc);
+        return 0.f;
+    }
+};
+
+template <>
+struct OpT<OP_FUSED> : OpBase {
+    static constexpr bool kDy = true;
+    static constexpr bool kStore = true;
+    static constexpr bool kReduce = true;
+    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t, float x, float dy, Acc& acc) {
+        float q, o;
+        fq_core(x, c.s, q, o);
+        nq_accumulate(q, o, dy, p.lam, acc);
+        return o;
+    }
+};
+
+// K5a forward: a = bits(max |P|/s), b = number of elements attaining it.
+template <>
+struct OpT<OP_MAXBIN_FWD> : OpBase {
+    static constexpr bool kReduce = true;
+    template <typename A, typename B>
+    __device__ static __forceinline__ void merge(A& x, const B& y) {
+        if (y.a > x.a) {
+            x.a = y.a;
+            x.b = y.b;
+        } else if (y.a == x.a) {
+            x.b += y.b;
+        }
+    }
+    __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc& acc) {
+        float t = fabsf(x) / c.s;                       // custom_loss_functions.py:92
+        uint32_t tb = __float_as_uint(fabsf(t));        // s > 0 in practice; |.| keeps the bit trick valid if not
+        if (tb > acc.a) {
+            acc.a = tb;
+            acc.b = 1u;
+        } else if (tb == acc.a) {
+            acc.b += 1u;
+        }
+        return 0.f;
+    }
+};
+
+// K5a backward: dP_i = (|P_i|/s == mb) ? sign(P_i) * coef / s : 0, coef = c / (G * ties)
+template <>
+struct OpT<OP_MAXBIN_BWD> : OpBase {
+    static constexpr bool kStore = true;
+    __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) {
+        Ctx c;
+        c.s = p.s[g];
+        c.k0 = p.mb[g];
+        float up = p.c_dev[0] * p.c_scale;
+        c.k1 = (up / (float)p.G) / (float)p.ties[g];
+        return c;
+    }
+    __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc&) {
+        float t = fabsf(fabsf(x) / c.s);
+        float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+        return (t == c.k0) ? (c.k1 / c.s) * sgn : 0.f;
+    }
+};
+
+// K5b forward: c = sum |P - P/s|
+template <>
+struct OpT<OP_DIFF_FWD> : OpBase {
+    static constexpr bool kReduce = true;
+    __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc& acc) {
+        float pq = x / c.s;                             // custom_loss_functions.py:172
+        acc.c += fabsf(x - pq);                         // :175
+        return 0.f;
+    }
+};
+
+// K5b backward: gi = sign(u) * c/N ; dP = gi - gi/s ; ds[g] = sum gi * (P/s) / s
+template <>
+struct OpT<OP_DIFF_BWD> : OpBase {
+    static constexpr bool kStore = true;
+    static constexpr bool kReduce = true;
+    __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) {
+        Ctx c;
+        c.s = p.s[g];
+        double n = (double)p.outer * (double)p.G * (double)p.inner;
+        c.k0 = (p.c_dev[0] * p.c_scale) / (float)n;
+        c.k1 = 0.f;
+        return c;
+    }
+    __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc& acc) {
+        float pq = x / c.s;
+        float u = x - pq;
+        float sgn = (u > 0.f) ? 1.f : ((u < 0.f) ? -1.f : 0.f);
+        float gi = sgn * c.k0;
+        acc.c += (gi * pq) / c.s;
+        return gi - gi / c.s;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+//  Reductions: wave butterfly (64 lanes) -> LDS across the block's waves.
+// ------------------------------------------------------------------------------------------
+template <class O, class A>
+__device__ __forceinline__ void wave_reduce(A& acc, int width = 64) {
+    for (int off = width >> 1; off > 0; off >>= 1) {
+        A o;
+        o.a = __shfl_xor(acc.a, off, 64);
+        o.b = __shfl_xor(acc.b, off, 64);
+        o.c = __shfl_xor(acc.c, off, 64);
+        O::merge(acc, o);
+    }
+}
+
+// Result valid in thread 0.  BS = block size (multiple of 64).
+template <class O, class A, int BS>
+__device__ __forceinline__ void block_reduce(A& acc) {
+    __shared__ A lds[BS / 64];
+    wave_reduce<O>(acc);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) lds[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        A r = lds[0];
+#pragma unroll
+        for (int w = 1; w < BS / 64; ++w) O::merge(r, lds[w]);
+        acc = r;
+    }
+}
+
+__device__ __forceinline__ void write_partial(const Params& p, int64_t idx, const Acc& acc) {
+    p.pa[idx] = acc.a;
+    p.pb[idx] = acc.b;
+    p.pc[idx] = acc.c;
+}
+
+// ------------------------------------------------------------------------------------------
+//  Traversal 1 -- "row big": rows of length L >= 1024; one block per (row, chunk) unit.
+//  The scale is block-uniform.  VEC = 4: float4 loads/stores (L % 4 == 0, 16-B aligned bases).
+// ------------------------------------------------------------------------------------------
+template <int OP, int VEC>
+__global__ __launch_bounds__(kBlock) void k_row_big(Params p, int64_t L, int CH, int64_t nc) {
+    using O = OpT<OP>;
+    const int64_t unit = blockIdx.x;
+    const int64_t row = unit / nc;
+    const int64_t ck = unit - row * nc;
+    const int64_t g = row % p.G;
+    const Ctx ctx = O::ctx(p, g);
+    const int64_t base = row * L + ck * (int64_t)CH;
+    const int64_t rem = L - ck * (int64_t)CH;
+    const int len = rem < (int64_t)CH ? (int)rem : CH;
+    Acc acc = O::template init<Acc>();
+
+    if (VEC == 4) {
+        const float4* P4 = reinterpret_cast<const float4*>(p.P + base);
+        const float4* D4 = reinterpret_cast<const float4*>(O::kDy ? p.dy + base : p.P + base);
+        float4* O4 = reinterpret_cast<float4*>(O::kStore ? p.out + base : nullptr);
+        const int len4 = len >> 2;
+        for (int it = 0; it < len4; it += kBlock * kUnroll) {
+            float4 x[kUnroll], d[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int j = it + u * kBlock + (int)threadIdx.x;
+                if (j < len4) {
+                    x[u] = P4[j];
+                    if (O::kDy) d[u] = D4[j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int j = it + u * kBlock + (int)threadIdx.x;
+                if (j < len4) {
+                    const int64_t i = base + (int64_t)j * 4;
+                    float4 r;
+                    r.x = O::elem(p, ctx, i + 0, x[u].x, O::kDy ? d[u].x : 0.f, acc);
+                    r.y = O::elem(p, ctx, i + 1, x[u].y, O::kDy ? d[u].y : 0.f, acc);
+                    r.z = O::elem(p, ctx, i + 2, x[u].z, O::kDy ? d[u].z : 0.f, acc);
+                    r.w = O::elem(p, ctx, i + 3, x[u].w, O::kDy ? d[u].w : 0.f, acc);
+                    if (O::kStore) O4[j] = r;
+                }
+            }
+        }
+        // ragged tail (only a single flat row, G == 1, can have len % 4 != 0 on the vector path)
+        const int tail = len & 3;
+        if ((int)threadIdx.x < tail) {
+            const int64_t i = base + (int64_t)len4 * 4 + threadIdx.x;
+            float r = O::elem(p, ctx, i, p.P[i], O::kDy ? p.dy[i] : 0.f, acc);
+            if (O::kStore) p.out[i] = r;
+        }
+    } else {
+        for (int it = 0; it < len; it += kBlock * kUnroll) {
+            float x[kUnroll], d[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int j = it + u * kBlock + (int)threadIdx.x;
+                if (j < len) {
+                    x[u] = p.P[base + j];
+                    if (O::kDy) d[u] = p.dy[base + j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int j = it + u * kBlock + (int)threadIdx.x;
+                if (j < len) {
+                    float r = O::elem(p, ctx, base + j, x[u], O::kDy ? d[u] : 0.f, acc);
+                    if (O::kStore) p.out[base + j] = r;
+                }
+            }
+        }
+    }
+    if (O::kReduce) {
+        block_reduce<O, Acc, kBlock>(acc);
+        if (threadIdx.x == 0) write_partial(p, unit, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Traversal 2 -- "row small": rows of length L < 1024.  A team of 2^lpr_log2 lanes (<= 64,
+//  inside one wave) owns a row; 256 >> lpr_log2 rows per block; one partial per row.
+// ------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_row_small(Params p, int64_t R, int L, int lpr_log2) {
+    using O = OpT<OP>;
+    const int lpr = 1 << lpr_log2;
+    const int team = (int)threadIdx.x >> lpr_log2;
+    const int lane = (int)threadIdx.x & (lpr - 1);
+    const int64_t row = (int64_t)blockIdx.x * (kBlock >> lpr_log2) + team;
+    const bool valid = row < R;
+    Acc acc = O::template init<Acc>();
+    if (valid) {
+        const Ctx ctx = O::ctx(p, row % p.G);
+        const int64_t base = row * (int64_t)L;
+#pragma unroll 4
+        for (int j = lane; j < L; j += lpr) {
+            const float x = p.P[base + j];
+            const float d = O::kDy ? p.dy[base + j] : 0.f;
+            float r = O::elem(p, ctx, base + j, x, d, acc);
+            if (O::kStore) p.out[base + j] = r;
+        }
+    }
+    if (O::kReduce) {
+        wave_reduce<O>(acc, lpr);   // all 64 lanes execute the shuffles; teams never mix (xor < lpr)
+        if (valid && lane == 0) write_partial(p, row, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Traversal 3 -- "column": inner < 16 and outer > 1.  The tensor is a matrix [outer][C],
+//  C = G*inner; a thread owns a column (coalesced across the wave) and walks a slice of rows.
+// ------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_col(Params p, int64_t C, int64_t rps) {
+    using O = OpT<OP>;
+    const int64_t col = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (col >= C) return;   // no block-level synchronisation below
+    const int64_t y = blockIdx.y;
+    const Ctx ctx = O::ctx(p, col / p.inner);
+    const int64_t r0 = y * rps;
+    const int64_t r1 = (r0 + rps < p.outer) ? r0 + rps : p.outer;
+    Acc acc = O::template init<Acc>();
+#pragma unroll 4
+    for (int64_t r = r0; r < r1; ++r) {
+        const int64_t i = r * C + col;
+        const float x = p.P[i];
+        const float d = O::kDy ? p.dy[i] : 0.f;
+        float v = O::elem(p, ctx, i, x, d, acc);
+        if (O::kStore) p.out[i] = v;
+    }
+    if (O::kReduce) write_partial(p, y * C + col, acc);
+}
+
+// ------------------------------------------------------------------------------------------
+//  Finalize: merge the partials of each group in a fixed order (wide accumulator) and emit.
+//  Partial index of group g:  g*gstride + i1*stride1 + i2 ,  i1 < n1, i2 < n2.
+// ------------------------------------------------------------------------------------------
+struct FinGeom {
+    int64_t groups;
+    int64_t gstride, n1, stride1, n2;
+    double count;        // elements per group (outer * inner), or numel for a global reduction
+    float* o0;           // op-specific outputs
+    float* o1;
+    uint32_t* o2;
+};
+
+template <int OP>
+struct FinT;
+
+template <>
+struct FinT<OP_BWD> {
+    __device__ static void emit(const Params& p, const FinGeom& f, int64_t g, const AccW& a) {
+        const float maxq = __uint_as_float(a.a);
+        float mean;
+        if (a.b == 0ull) {
+            mean = -1.0f * fabsf(tanhf(p.lam));                 // custom_layers.py:79 / :105
+        } else {
+            mean = (float)(a.c / f.count);                      // :87 / :113
+        }
+        f.o0[g] = mean * maxq;                                  // :116
+        if (f.o1) {
+            f.o1[g] = maxq;
+            f.o1[f.groups + g] = mean;
+            f.o1[2 * f.groups + g] = (float)a.b;
+        }
+    }
+};
+template <>
+struct FinT<OP_FUSED> : FinT<OP_BWD> {};
+
+template <>
+struct FinT<OP_MAXBIN_FWD> {
+    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
+        f.o0[g] = __uint_as_float(a.a);
+        f.o2[g] = (uint32_t)(a.b > 0xffffffffull ? 0xffffffffull : a.b);
+    }
+};
+
+template <>
+struct FinT<OP_DIFF_FWD> {
+    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
+        f.o0[g] = (float)(a.c / f.count);                       // custom_loss_functions.py:175 reduce_mean
+    }
+};
+
+template <>
+struct FinT<OP_DIFF_BWD> {
+    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
+        f.o0[g] = (float)a.c;
+    }
+};
+
+template <class O>
+__device__ __forceinline__ AccW load_partial(const Params& p, int64_t idx) {
+    AccW w;
+    w.a = p.pa[idx];
+    w.b = p.pb[idx];
+    w.c = (double)p.pc[idx];
+    return w;
+}
+
+// One block of BS threads per group.
+template <int OP, int BS>
+__global__ __launch_bounds__(BS) void k_finalize_block(Params p, FinGeom f) {
+    using O = OpT<OP>;
+    const int64_t g = blockIdx.x;
+    const int64_t n = f.n1 * f.n2;
+    AccW acc = O::template init<AccW>();
+    for (int64_t k = threadIdx.x; k < n; k += BS) {
+        const int64_t i1 = k / f.n2, i2 = k - i1 * f.n2;
+        O::merge(acc, load_partial<O>(p, g * f.gstride + i1 * f.stride1 + i2));
+    }
+    block_reduce<O, AccW, BS>(acc);
+    if (threadIdx.x == 0) FinT<OP>::emit(p, f, g, acc);
+}
+
+// One thread per group (few partials per group, possibly very many groups).
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_finalize_thread(Params p, FinGeom f) {
+    using O = OpT<OP>;
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= f.groups) return;
+    AccW acc = O::template init<AccW>();
+    for (int64_t i1 = 0; i1 < f.n1; ++i1)
+        for (int64_t i2 = 0; i2 < f.n2; ++i2) O::merge(acc, load_partial<O>(p, g * f.gstride + i1 * f.stride1 + i2));
+    FinT<OP>::emit(p, f, g, acc);
+}
+
+// ------------------------------------------------------------------------------------------
+//  Small vector kernels (scale-sized data).
+// ------------------------------------------------------------------------------------------
+// mode 0: out = mean(v[0..n))      mode 1: out = mean(1 / where(v==0, eps, v))
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_vec_mean(const float* v, int64_t n, float* out) {
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+        float x = v[i];
+        if (MODE == 1) {
+            float nz = (x == 0.0f) ? kEpsF32 : x;     // custom_loss_functions.py:252
+            x = 1.0f / nz;                            // :255
+        }
+        acc += (double)x;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ double lds[kWavesPerBlock];
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+        for (int w = 1; w < kWavesPerBlock; ++w) t += lds[w];
+        out[0] = (float)(t / (double)n);
+    }
+}
+
+__global__ void k_maxbin_ds(const float* s, const float* mb, const float* c_dev, float c_scale, float* ds, int64_t G) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const float up = c_dev[0] * c_scale;
+    // sum over ties of -(g_i) * t / s with g_i = up/(G*ties): = -(up/G) * mb / s
+    ds[g] = -((up / (float)G) * mb[g]) / s[g];
+}
+
+__global__ void k_inverse_bwd(const float* s, const float* c_dev, float c_scale, float* ds, int64_t G) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const float up = c_dev[0] * c_scale;
+    const float sg = s[g];
+    // d/ds mean(1/s) = -1/(G s^2); tf.where routes no gradient into s where s == 0
+    ds[g] = (sg == 0.0f) ? 0.0f : -((up / (float)G) / sg) / sg;
+}
+
+__global__ void k_adam(float* s, const float* ds, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                       float eps, float b1p, float b2p, float min_value, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = ds[i];
+    float mi = m[i], vi = v[i], w = s[i];
+    mi = mi + (g - mi) * (1.0f - b1);
+    vi = vi + (g * g - vi) * (1.0f - b2);
+    if (mode == LQ_ADAM_KERAS) {
+        const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+        w = w - (mi * alpha) / (sqrtf(vi) + eps);
+    } else {
+        const float mh = mi / (1.0f - b1p);
+        const float denom = sqrtf(vi) / sqrtf(1.0f - b2p) + eps;
+        w = w - lr * (mh / denom);
+    }
+    w = (w < min_value) ? min_value : w;   // MinValueConstraint: max(w, min_value); NaN stays NaN
+    m[i] = mi;
+    v[i] = vi;
+    s[i] = w;
+}
+
+__global__ void k_min_project(float* w, int64_t n, float min_value) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = w[i];
+    w[i] = (x < min_value) ? min_value : x;   // tf.maximum(w, min_value); NaN propagates
+}
+
+// result[a, b] = max over the middle axis of |floor(P/s)| for a tensor viewed (pre, n_axis, post)
+__global__ void k_q_absmax_axis(const float* P, const float* s, float* result, int64_t pre, int64_t n_axis, int64_t post,
+                                int64_t G, int64_t inner) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pre * post) return;
+    const int64_t a = t / post, b = t - a * post;
+    uint32_t best = 0u;
+    for (int64_t k = 0; k < n_axis; ++k) {
+        const int64_t i = (a * n_axis + k) * post + b;
+        const float sg = s[(i / inner) % G];
+        float q, o;
+        fq_core(P[i], sg, q, o);
+        const uint32_t bits = __float_as_uint(fabsf(q));
+        best = bits > best ? bits : best;
+    }
+    result[t] = __uint_as_float(best);
+}
+
+// ------------------------------------------------------------------------------------------
+//  Host side: plan, launchers, C ABI.
+// ------------------------------------------------------------------------------------------
+enum Mode { MODE_ROW_BIG = 0, MODE_ROW_SMALL = 1, MODE_COL = 2 };
+
+struct Plan {
+    int mode;
+    int64_t R, L;       // row modes
+    int CH;
+    int64_t nc;
+    int lpr_log2;
+    int64_t C, rps, ysplit;   // column mode
+    int64_t np;         // number of partial triples
+    // finalize geometry (per group)
+    int64_t gstride, n1, stride1, n2;
+};
+
+static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+static Plan make_plan(int64_t outer, int64_t G, int64_t inner) {
+    Plan pl;
+    memset(&pl, 0, sizeof(pl));
+    const int64_t N = outer * G * inner;
+    int64_t R, L, f_outer;
+    bool col = false;
+    if (G == 1) {
+        R = 1;
+        L = N;
+        f_outer = 1;
+    } else {
+        R = outer * G;
+        L = inner;
+        f_outer = outer;
+        if (inner < 16 && outer > 1) {
+            // column mode unless thread-per-row yields fewer partials
+            const int64_t C = G * inner;
+            int64_t threads = N / 16;
+            if (threads > 131072) threads = 131072;
+            if (threads < 1) threads = 1;
+            int64_t ys = threads / C;
+            if (ys < 1) ys = 1;
+            if (ys > outer) ys = outer;
+            if (ys > 65535) ys = 65535;
+            const int64_t rps = ceil_div(outer, ys);
+            ys = ceil_div(outer, rps);
+            if (ys * C <= R) {
+                col = true;
+                pl.mode = MODE_COL;
+                pl.C = C;
+                pl.rps = rps;
+                pl.ysplit = ys;
+                pl.np = ys * C;
+                pl.gstride = inner;
+                pl.n1 = ys;
+                pl.stride1 = C;
+                pl.n2 = inner;
+            }
+        }
+    }
+    if (!col) {
+        pl.R = R;
+        pl.L = L;
+        if (L >= 1024) {
+            pl.mode = MODE_ROW_BIG;
+            const int64_t nc0 = ceil_div(L, kChunkMax);
+            int64_t ch = ceil_div(ceil_div(L, nc0), 1024) * 1024;
+            pl.CH = (int)ch;
+            pl.nc = ceil_div(L, ch);
+        } else {
+            pl.mode = MODE_ROW_SMALL;
+            pl.CH = (int)L;
+            pl.nc = 1;
+            int lpr = 1, lg = 0;   // lanes per row = pow2floor(max(L/2, 1)) clipped to one wave
+            const int64_t half = L / 2 > 1 ? L / 2 : 1;
+            while (lpr * 2 <= half && lpr < 64) {
+                lpr *= 2;
+                ++lg;
+            }
+            pl.lpr_log2 = lg;
+        }
+        pl.np = R * pl.nc;
+        pl.gstride = pl.nc;
+        pl.n1 = f_outer;
+        pl.stride1 = G * pl.nc;
+        pl.n2 = pl.nc;
+    }
+    return pl;
+}
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int check_hip(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(LQ_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return LQ_OK;
+}
+
+static bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+static int check_desc(int64_t outer, int64_t G, int64_t inner) {
+    if (outer <= 0 || G <= 0 || inner <= 0) return fail(LQ_EINVAL, "descriptor extents must be positive (outer=%lld G=%lld inner=%lld)", (long long)outer, (long long)G, (long long)inner);
+    const double n = (double)outer * (double)G * (double)inner;
+    if (n > 9.0e15) return fail(LQ_EINVAL, "tensor too large");
+    return LQ_OK;
+}
+
+static size_t ws_bytes_for(const Plan& pl) {
+    size_t np = (size_t)pl.np;
+    np = (np + 63) / 64 * 64;
+    return np * 12 + 256;
+}
+
+static int bind_ws(Params& p, const Plan& pl, void* ws, size_t ws_bytes) {
+    if (!ws) return fail(LQ_EWORKSPACE, "workspace is NULL (need %zu bytes)", ws_bytes_for(pl));
+    if (!aligned(ws, 16)) return fail(LQ_EALIGN, "workspace must be 16-byte aligned");
+    if (ws_bytes < ws_bytes_for(pl)) return fail(LQ_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, ws_bytes_for(pl));
+    size_t np = ((size_t)pl.np + 63) / 64 * 64;
+    p.pa = reinterpret_cast<uint32_t*>(ws);
+    p.pb = p.pa + np;
+    p.pc = reinterpret_cast<float*>(p.pb + np);
+    return LQ_OK;
+}
+
+template <int OP>
+static int launch_traverse(const Plan& pl, const Params& p, hipStream_t st) {
+    using O = OpT<OP>;
+    if (pl.mode == MODE_ROW_BIG) {
+        const int64_t units = pl.R * pl.nc;
+        if (units > 2147483647ll) return fail(LQ_EINVAL, "too many work units (%lld)", (long long)units);
+        bool vec = (pl.L % 4 == 0 || pl.R == 1) && aligned(p.P, 16) && (!O::kDy || aligned(p.dy, 16)) && (!O::kStore || aligned(p.out, 16));
+        if (vec)
+            hipLaunchKernelGGL((k_row_big<OP, 4>), dim3((unsigned)units), dim3(kBlock), 0, st, p, pl.L, pl.CH, pl.nc);
+        else
+            hipLaunchKernelGGL((k_row_big<OP, 1>), dim3((unsigned)units), dim3(kBlock), 0, st, p, pl.L, pl.CH, pl.nc);
+    } else if (pl.mode == MODE_ROW_SMALL) {
+        const int rpb = kBlock >> pl.lpr_log2;
+        const int64_t blocks = ceil_div(pl.R, rpb);
+        if (blocks > 2147483647ll) return fail(LQ_EINVAL, "too many blocks (%lld)", (long long)blocks);
+        hipLaunchKernelGGL((k_row_small<OP>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L, pl.lpr_log2);
+    } else {
+        const int64_t bx = ceil_div(pl.C, kBlock);
+        if (bx > 2147483647ll) return fail(LQ_EINVAL, "too many blocks (%lld)", (long long)bx);
+        hipLaunchKernelGGL((k_col<OP>), dim3((unsigned)bx, (unsigned)pl.ysplit), dim3(kBlock), 0, st, p, pl.C, pl.rps);
+    }
+    return check_hip("traversal launch");
+}
+
+template <int OP>
+static int launch_finalize(const Params& p, FinGeom f, hipStream_t st) {
+    const int64_t n = f.n1 * f.n2;
+    if (n <= 32) {
+        hipLaunchKernelGGL((k_finalize_thread<OP>), dim3((unsigned)ceil_div(f.groups, kBlock)), dim3(kBlock), 0, st, p, f);
+    } else if (n <= 512) {
+        hipLaunchKernelGGL((k_finalize_block<OP, 64>), dim3((unsigned)f.groups), dim3(64), 0, st, p, f);
+    } else if (n <= 4096) {
+        hipLaunchKernelGGL((k_finalize_block<OP, 256>), dim3((unsigned)f.groups), dim3(256), 0, st, p, f);
+    } else {
+        hipLaunchKernelGGL((k_finalize_block<OP, 1024>), dim3((unsigned)f.groups), dim3(1024), 0, st, p, f);
+    }
+    return check_hip("finalize launch");
+}
+
+static FinGeom group_geom(const Plan& pl, int64_t outer, int64_t G, int64_t inner) {
+    FinGeom f;
+    memset(&f, 0, sizeof(f));
+    f.groups = G;
+    f.gstride = pl.gstride;
+    f.n1 = pl.n1;
+    f.stride1 = pl.stride1;
+    f.n2 = pl.n2;
+    f.count = (double)outer * (double)inner;
+    return f;
+}
+
+static FinGeom global_geom(const Plan& pl, int64_t outer, int64_t G, int64_t inner) {
+    FinGeom f;
+    memset(&f, 0, sizeof(f));
+    f.groups = 1;
+    f.gstride = 0;
+    f.n1 = 1;
+    f.stride1 = 0;
+    f.n2 = pl.np;
+    f.count = (double)outer * (double)G * (double)inner;
+    return f;
+}
+
+static Params base_params(const float* P, const float* s, int64_t outer, int64_t G, int64_t inner) {
+    Params p;
+    memset(&p, 0, sizeof(p));
+    p.P = P;
+    p.s = s;
+    p.outer = outer;
+    p.G = G;
+    p.inner = inner;
+    return p;
+}
+
+}  // namespace lq
+
+using namespace lq;
+
+#define LQ_REQUIRE_PTR(x)                                                      \
+    do {                                                                       \
+        if (!(x)) return fail(LQ_EINVAL, "%s: argument '%s' is NULL", __func__, #x); \
+        if (!aligned((x), 4)) return fail(LQ_EALIGN, "%s: argument '%s' is not 4-byte aligned", __func__, #x); \
+    } while (0)
+
+extern "C" {
+
+int lq_version(void) { return LQ_ABI_VERSION; }
+
+const char* lq_last_error(void) { return g_err; }
+
+const char* lq_status_string(int status) {
+    switch (status) {
+        case LQ_OK: return "LQ_OK";
+        case LQ_EINVAL: return "LQ_EINVAL";
+        case LQ_EHIP: return "LQ_EHIP";
+        case LQ_EWORKSPACE: return "LQ_EWORKSPACE";
+        case LQ_EALIGN: return "LQ_EALIGN";
+        default: return "LQ_UNKNOWN";
+    }
+}
+
+size_t lq_workspace_bytes(int64_t outer, int64_t G, int64_t inner) {
+    if (outer <= 0 || G <= 0 || inner <= 0) return 0;
+    return ws_bytes_for(make_plan(outer, G, inner));
+}
+
+int lq_fq_forward(const float* P, const float* s, float* out, void* q, int q_dtype, int64_t outer, int64_t G,
+                  int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    if (!out && !q) return fail(LQ_EINVAL, "lq_fq_forward: both out and q are NULL");
+    if (q_dtype < LQ_Q_NONE || q_dtype > LQ_Q_I8) return fail(LQ_EINVAL, "lq_fq_forward: bad q_dtype %d", q_dtype);
+    if ((q != nullptr) != (q_dtype != LQ_Q_NONE)) return fail(LQ_EINVAL, "lq_fq_forward: q and q_dtype disagree");
+    Plan pl = make_plan(outer, G, inner);
+    Params p = base_params(P, s, outer, G, inner);
+    p.q = q;
+    p.q_dtype = q_dtype;
+    if (out) {
+        if (!aligned(out, 4)) return fail(LQ_EALIGN, "lq_fq_forward: out is not 4-byte aligned");
+        p.out = out;
+        return launch_traverse<OP_FWD>(pl, p, (hipStream_t)stream);
+    }
+    return launch_traverse<OP_QONLY>(pl, p, (hipStream_t)stream);
+}
+
+int lq_fq_scale_grad(const float* P, const float* s, const float* dy, float lambda, float* ds, float* parts, void* ws,
+                     size_t ws_bytes, int64_t outer, int64_t G, int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(dy);
+    LQ_REQUIRE_PTR(ds);
+    Plan pl = make_plan(outer, G, inner);
+    Params p = base_params(P, s, outer, G, inner);
+    p.dy = dy;
+    p.lam = lambda;
+    if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
+    if ((rc = launch_traverse<OP_BWD>(pl, p, (hipStream_t)stream))) return rc;
+    FinGeom f = group_geom(pl, outer, G, inner);
+    f.o0 = ds;
+    f.o1 = parts;
+    return launch_finalize<OP_BWD>(p, f, (hipStream_t)stream);
+}
+
+int lq_fq_fwd_bwd_fused(const float* P, const float* s, const float* dy, float lambda, float* out, float* ds, void* ws,
+                        size_t ws_bytes, int64_t outer, int64_t G, int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(dy);
+    LQ_REQUIRE_PTR(out);
+    LQ_REQUIRE_PTR(ds);
+    Plan pl = make_plan(outer, G, inner);
+    Params p = base_params(P, s, outer, G, inner);
+    p.dy = dy;
+    p.lam = lambda;
+    p.out = out;
+    if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
+    if ((rc = launch_traverse<OP_FUSED>(pl, p, (hipStream_t)stream))) return rc;
+    FinGeom f = group_geom(pl, outer, G, inner);
+    f.o0 = ds;
+    return launch_finalize<OP_FUSED>(p, f, (hipStream_t)stream);
+}
+
+int lq_penalty_maxbin_fwd(const float* P, const float* s, float* mb, uint32_t* ties, float* term, void* ws,
+                          size_t ws_bytes, int64_t outer, int64_t G, int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(mb);
+    LQ_REQUIRE_PTR(ties);
+    LQ_REQUIRE_PTR(term);
+    Plan pl = make_plan(outer, G, inner);
+    Params p = base_params(P, s, outer, G, inner);
+    if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
+    if ((rc = launch_traverse<OP_MAXBIN_FWD>(pl, p, (hipStream_t)stream))) return rc;
+    FinGeom f = group_geom(pl, outer, G, inner);
+    f.o0 = mb;
+    f.o2 = ties;
+    if ((rc = launch_finalize<OP_MAXBIN_FWD>(p, f, (hipStream_t)stream))) return rc;
+    hipLaunchKernelGGL((k_vec_mean<0>), dim3(1), dim3(kBlock), 0, (hipStream_t)stream, mb, G, term);   // :110 reduce_mean(maxbin)
+    return check_hip("maxbin mean launch");
+}
+
+int lq_penalty_maxbin_bwd(const float* P, const float* s, const float* mb, const uint32_t* ties, const float* c_dev,
+                          float c_scale, float* dP, float* ds, int64_t outer, int64_t G, int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(mb);
+    LQ_REQUIRE_PTR(ties);
+    LQ_REQUIRE_PTR(c_dev);
+    LQ_REQUIRE_PTR(dP);
+    LQ_REQUIRE_PTR(ds);
+    Plan pl = make_plan(outer, G, inner);
+    Params p = base_params(P, s, outer, G, inner);
+    p.mb = mb;
+    p.ties = ties;
+    p.c_dev = c_dev;
+    p.c_scale = c_scale;
+    p.out = dP;
+    if ((rc = launch_traverse<OP_MAXBIN_BWD>(pl, p, (hipStream_t)stream))) return rc;
+    hipLaunchKernelGGL(k_maxbin_ds, dim3((unsigned)ceil_div(G, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, s, mb, c_dev, c_scale, ds, G);
+    return check_hip("maxbin ds launch");
+}
+
+int lq_penalty_difference_fwd(const float* P, const float* s, float* term, void* ws, size_t ws_bytes, int64_t outer,
+                              int64_t G, int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(term);
+    Plan pl = make_plan(outer, G, inner);
+    Params p = base_params(P, s, outer, G, inner);
+    if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
+    if ((rc = launch_traverse<OP_DIFF_FWD>(pl, p, (hipStream_t)stream))) return rc;
+    FinGeom f = global_geom(pl, outer, G, inner);
+    f.o0 = term;
+    return launch_finalize<OP_DIFF_FWD>(p, f, (hipStream_t)stream);
+}
+
+int lq_penalty_difference_bwd(const float* P, const float* s, const float* c_dev, float c_scale, float* dP, float* ds,
+                              void* ws, size_t ws_bytes, int64_t outer, int64_t G, int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(c_dev);
+    LQ_REQUIRE_PTR(dP);
+    LQ_REQUIRE_PTR(ds);
+    Plan pl = make_plan(outer, G, inner);
+    Params p = base_params(P, s, outer, G, inner);
+    p.c_dev = c_dev;
+    p.c_scale = c_scale;
+    p.out = dP;
+    if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
+    if ((rc = launch_traverse<OP_DIFF_BWD>(pl, p, (hipStream_t)stream))) return rc;
+    FinGeom f = group_geom(pl, outer, G, inner);
+    f.o0 = ds;
+    return launch_finalize<OP_DIFF_BWD>(p, f, (hipStream_t)stream);
+}
+
+int lq_penalty_inverse_fwd(const float* s, float* term, int64_t G, void* stream) {
+    if (G <= 0) return fail(LQ_EINVAL, "lq_penalty_inverse_fwd: G must be positive");
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(term);
+    hipLaunchKernelGGL((k_vec_mean<1>), dim3(1), dim3(kBlock), 0, (hipStream_t)stream, s, G, term);
+    return check_hip("inverse fwd launch");
+}
+
+int lq_penalty_inverse_bwd(const float* s, const float* c_dev, float c_scale, float* ds, int64_t G, void* stream) {
+    if (G <= 0) return fail(LQ_EINVAL, "lq_penalty_inverse_bwd: G must be positive");
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(c_dev);
+    LQ_REQUIRE_PTR(ds);
+    hipLaunchKernelGGL(k_inverse_bwd, dim3((unsigned)ceil_div(G, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, s, c_dev, c_scale, ds, G);
+    return check_hip("inverse bwd launch");
+}
+
+int lq_scale_adam_step(float* s, const float* ds, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, int64_t step, float min_value, int mode, void* stream) {
+    if (n <= 0) return fail(LQ_EINVAL, "lq_scale_adam_step: n must be positive");
+    if (step < 1) return fail(LQ_EINVAL, "lq_scale_adam_step: step is 1-based");
+    if (mode != LQ_ADAM_KERAS && mode != LQ_ADAM_TORCH) return fail(LQ_EINVAL, "lq_scale_adam_step: bad mode %d", mode);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(ds);
+    LQ_REQUIRE_PTR(m);
+    LQ_REQUIRE_PTR(v);
+    const float b1p = powf(beta1, (float)step), b2p = powf(beta2, (float)step);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, s, ds, m, v, n, lr, beta1, beta2, eps, b1p, b2p, min_value, mode);
+    return check_hip("adam launch");
+}
+
+int lq_min_value_project(float* w, int64_t n, float min_value, void* stream) {
+    if (n <= 0) return fail(LQ_EINVAL, "lq_min_value_project: n must be positive");
+    LQ_REQUIRE_PTR(w);
+    hipLaunchKernelGGL(k_min_project, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, w, n, min_value);
+    return check_hip("min project launch");
+}
+
+int lq_q_absmax_over_axis(const float* P, const float* s, float* result, int64_t pre, int64_t n_axis, int64_t post,
+                          int64_t outer, int64_t G, int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    if (pre <= 0 || n_axis <= 0 || post <= 0 || pre * n_axis * post != outer * G * inner)
+        return fail(LQ_EINVAL, "lq_q_absmax_over_axis: (pre,n_axis,post) does not match the tensor");
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(result);
+    hipLaunchKernelGGL(k_q_absmax_axis, dim3((unsigned)ceil_div(pre * post, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, P, s, result, pre, n_axis, post, G, inner);
+    return check_hip("absmax axis launch");
+}
+
+}  // extern "C"

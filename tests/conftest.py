@@ -1,0 +1,77 @@
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _load_npz_cases(path):
+    z = np.load(path)
+    cases = {}
+    for k in z.files:
+        name, field = k.split("/")
+        cases.setdefault(name, {})[field] = z[k]
+    return cases
+
+
+@pytest.fixture(scope="session")
+def golden_cases():
+    return _load_npz_cases(os.path.join(GOLDEN, "golden_cases.npz"))
+
+
+@pytest.fixture(scope="session")
+def kat():
+    with open(os.path.join(GOLDEN, "kat_survey.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def mnist_weights():
+    return dict(np.load(os.path.join(GOLDEN, "mnist_baseline_weights.npz")))
+
+
+@pytest.fixture(scope="session")
+def mnist_expected():
+    with open(os.path.join(GOLDEN, "mnist_expected.json")) as f:
+        meta = json.load(f)
+    return meta, dict(np.load(os.path.join(GOLDEN, "mnist_expected.npz")))
+
+
+@pytest.fixture(scope="session")
+def c_oracle():
+    """The scalar C restatement (oracle/lq_oracle.c), built on demand with gcc."""
+    so = os.path.join(ROOT, "oracle", "liblq_oracle.so")
+    src = os.path.join(ROOT, "oracle", "lq_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    lib = ctypes.CDLL(so)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    i64 = ctypes.c_int64
+    lib.lqo_fq_forward.argtypes = [f32p, f32p, f32p, f32p, i64, i64, i64]
+    lib.lqo_fq_forward.restype = None
+    lib.lqo_nq_scale_grad.argtypes = [f32p, f32p, f32p, ctypes.c_float, f32p, f32p, f32p,
+                                      ctypes.POINTER(ctypes.c_int64), i64, i64, i64]
+    lib.lqo_nq_scale_grad.restype = None
+    for name in ("lqo_maxbin_term", "lqo_difference_term"):
+        fn = getattr(lib, name)
+        fn.argtypes = [f32p, f32p, i64, i64, i64]
+        fn.restype = ctypes.c_float
+    lib.lqo_inverse_term.argtypes = [f32p, i64]
+    lib.lqo_inverse_term.restype = ctypes.c_float
+    return lib
+
+
+def as_f32p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
