@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the fake-quant training path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload: synthetic conv-activation batch
+256 x 3 x 224 x 224 fp32 per GPU (x ~ U[0,255), dy ~ N(0,1e-3), seed 42), per-channel scales
+s = [0.5, 1, 2] (outer=256, G=3, inner=50176), threshold lambda = 1e-3.
+One STEP = what one training iteration does to that tensor on the hot path, through the C ABI:
+    forward   lq_fq_forward      out = floor(x/s)*s                    (K1, 8 B/element)
+    backward  lq_fq_scale_grad   ds = mean_g(vote) * max_g|q|          (K2+K3, 8 B/element; dP aliases dy)
+  = 16 algorithmic bytes per element, 616.6 MB per step.  Inputs are resident in HBM before the
+timed region; >= 4 buffer sets (>= 1.8 GB) rotate so the 256 MiB Infinity Cache cannot serve re-reads.
+With N > 1 ranks (one process per GPU, torch.distributed "nccl" = RCCL over xGMI) every rank
+processes its own 256-image shard (weak scaling) and the learned-scale gradient is all-reduced
+each step -- the only exchange this path has.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  "roofline":     dominant kernel vs the 8 TB/s HBM peak, duration from HIP events inside the timed region
+  "cpu_baseline": the op-for-op torch-CPU restatement of the reference path (oracle/lq_oracle_torch.py)
+                  timed on this box's host cores on a bounded sample -- a baseline, not a target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BATCH, CH, H, W = 256, 3, 224, 224
+ELEMS = BATCH * CH * H * W                      # 38,535,168
+BYTES_FWD = 8 * ELEMS                           # 4 R + 4 W
+BYTES_BWD = 8 * ELEMS                           # 4 R (dy) + 4 R (x recompute); dP aliases dy
+BYTES_FUSED = 12 * ELEMS                        # K4 single pass: x and dy read once, out written
+HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--lam", type=float, default=1e-3)
+    ap.add_argument("--variant", choices=["split", "fused"], default="split",
+                    help="split = K1 then K2+K3 (what autograd runs); fused = K4 single pass")
+    ap.add_argument("--scale", choices=["per_channel", "per_tensor"], default="per_channel")
+    ap.add_argument("--sets", type=int, default=4, help="rotating buffer sets (>= 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(lam: float, budget_s: float):
+    """Reference-equivalent CPU path (restated; TF 2.11 unavailable): unfused op sequence in torch-CPU."""
+    from oracle import lq_oracle_torch as OT
+    n_img = 32
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(n_img, CH, H, W, generator=g) * 255.0
+    dy = torch.randn(n_img, CH, H, W, generator=g) * 1e-3
+    s = torch.tensor([0.5, 1.0, 2.0]).view(1, CH, 1, 1)
+    OT.nq_forward_backward(x, s, lam, dy)                       # warm
+    t0 = time.perf_counter()
+    OT.nq_forward_backward(x, s, lam, dy)
+    t1 = time.perf_counter() - t0
+    reps = int(min(max(budget_s / max(t1, 1e-6), 3), 400))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        OT.nq_forward_backward(x, s, lam, dy)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_img * reps / dt,
+        "unit": "images/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{reps} x (fwd+bwd of {n_img}x3x224x224 fp32, lambda={lam:g}) = {dt:.1f} s; "
+                  f"oracle/lq_oracle_torch.py unfused op sequence; os.cpu_count()={os.cpu_count()}",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from learned_quantization_amd import _hip
+    lib = _hip.load()
+
+    # ---------------- inputs resident in HBM before the timed region
+    nsets = max(4, args.sets)
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    xs = [torch.rand(BATCH, CH, H, W, device=dev, generator=g) * 255.0 for _ in range(nsets)]
+    dys = [torch.randn(BATCH, CH, H, W, device=dev, generator=g) * 1e-3 for _ in range(nsets)]
+    outs = [torch.empty(BATCH, CH, H, W, device=dev) for _ in range(nsets)]
+    if args.scale == "per_channel":
+        s = torch.tensor([0.5, 1.0, 2.0], device=dev).view(1, CH, 1, 1)
+        outer, G, inner = BATCH, CH, H * W
+    else:
+        s = torch.tensor([1.0], device=dev)
+        outer, G, inner = 1, 1, ELEMS
+    ds = torch.zeros_like(s)
+    ws_bytes = lib.lq_workspace_bytes(outer, G, inner)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sp = stream.cuda_stream or None
+    lam = float(args.lam)
+    px = [t.data_ptr() for t in xs]
+    pdy = [t.data_ptr() for t in dys]
+    pout = [t.data_ptr() for t in outs]
+    ps, pds, pws = s.data_ptr(), ds.data_ptr(), ws.data_ptr()
+
+    fwd, bwd, fused = lib.lq_fq_forward, lib.lq_fq_scale_grad, lib.lq_fq_fwd_bwd_fused
+
+    def step(i, ev=None):
+        k = i % nsets
+        if args.variant == "split":
+            if ev:
+                ev[0].record(stream)
+            rc = fwd(px[k], ps, pout[k], None, 0, outer, G, inner, sp)
+            if ev:
+                ev[1].record(stream)
+            rc |= bwd(px[k], ps, pdy[k], lam, pds, None, pws, ws_bytes, outer, G, inner, sp)
+            if ev:
+                ev[2].record(stream)
+        else:
+            if ev:
+                ev[0].record(stream)
+            rc = fused(px[k], ps, pdy[k], lam, pout[k], pds, pws, ws_bytes, outer, G, inner, sp)
+            if ev:
+                ev[2].record(stream)
+        if rc:
+            _hip.check(rc, "bench step")
+        if world > 1:
+            dist.all_reduce(ds, op=dist.ReduceOp.SUM)     # learned-scale gradient exchange (mode A)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, events[i])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations from the HIP events recorded inside the timed region
+    if args.variant == "split":
+        t_fwd = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps * 1e-3
+        t_bwd = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps * 1e-3
+        if t_bwd >= t_fwd:
+            kname, kbytes, kt = "k_row_big<OP_BWD> (+finalize)", BYTES_BWD, t_bwd
+        else:
+            kname, kbytes, kt = "k_row_big<OP_FWD>", BYTES_FWD, t_fwd
+        step_bytes = BYTES_FWD + BYTES_BWD
+        extra = {"t_fwd_us": t_fwd * 1e6, "t_bwd_us": t_bwd * 1e6,
+                 "fwd_GBs": BYTES_FWD / t_fwd / 1e9, "bwd_GBs": BYTES_BWD / t_bwd / 1e9}
+    else:
+        kt = sum(e[0].elapsed_time(e[2]) for e in events) / args.steps * 1e-3
+        kname, kbytes = "k_row_big<OP_FUSED> (+finalize)", BYTES_FUSED
+        step_bytes = BYTES_FUSED
+        extra = {"t_fused_us": kt * 1e6}
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f).get(args.variant, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * BATCH * args.steps / elapsed
+        achieved = kbytes / kt / 1e9
+        line = {
+            "metric": "images/sec training with fake-quant layer, CIFAR-10 bs=256, 1/2/4/8 MI355X",
+            "value": value,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"fake-quant fwd+bwd ({args.variant}) on conv-activation batch 256x3x224x224 fp32 per GPU, "
+                                   f"{args.scale} scales, lambda={lam:g}",
+                       "per_gpu_batch": BATCH, "global_batch": BATCH * world, "parallelism": f"dp{world}",
+                       "buffer_sets": nsets, "algorithmic_bytes_per_step": step_bytes,
+                       "step_GBs": step_bytes / (elapsed / args.steps) / 1e9},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_us": kt * 1e6, **extra},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(lam, args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

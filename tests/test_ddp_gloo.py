@@ -1,0 +1,143 @@
+"""World-size-2 gloo tests of the data-parallel exchange step (CPU; the kernel is replaced by the ORACLE,
+in the test only, so that the bucket / ordering logic of learned_quantization_amd/ddp.py is exercised)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _FakeNested(torch.nn.Module):
+    def __init__(self, shape, lam):
+        super().__init__()
+        self.scale = torch.nn.Parameter(torch.full(shape, 0.01))
+        self.scale.lq_is_scale = True
+        self.penalty_threshold = lam
+
+
+class _FakeLayer(torch.nn.Module):
+    """Same attribute surface as CustomDenseLayer (W, b, nested_q_w_layer, nested_q_b_layer); the fake-quant op is
+    replaced by an oracle-backed autograd function so the test runs without a GPU."""
+
+    def __init__(self, lam):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.W = torch.nn.Parameter(torch.randn(12, 5, generator=g) * 0.05)
+        self.b = torch.nn.Parameter(torch.randn(5, generator=g) * 0.05)
+        self.nested_q_w_layer = _FakeNested((12, 1), lam)
+        self.nested_q_b_layer = _FakeNested((1,), lam)
+
+    def forward(self, x):
+        return x @ _OracleNQ.apply(self.W, self.nested_q_w_layer.scale, self.nested_q_w_layer.penalty_threshold) + \
+            _OracleNQ.apply(self.b, self.nested_q_b_layer.scale, self.nested_q_b_layer.penalty_threshold)
+
+
+class _OracleNQ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, P, s, lam):
+        from oracle import lq_oracle as O
+        ctx.save_for_backward(P, s)
+        ctx.lam = lam
+        return torch.from_numpy(O.fq_forward(P.detach().numpy(), s.detach().numpy())[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from oracle import lq_oracle as O
+        P, s = ctx.saved_tensors
+        _, ds = O.nq_backward(P.detach().numpy(), s.detach().numpy(), ctx.lam, dy.numpy())
+        return dy, torch.from_numpy(ds), None
+
+
+def _oracle_scale_grad(P, s, dy, lam):
+    from oracle import lq_oracle as O
+    return torch.from_numpy(O.nq_backward(P.numpy(), s.numpy(), lam, dy.numpy())[1])
+
+
+def _worker(rank, world, port, mode, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from learned_quantization_amd.ddp import DataParallel
+    lam = 2e-2
+    model = _FakeLayer(lam)
+    if rank == 1:   # replicas start different on purpose: the wrapper must broadcast rank 0's
+        with torch.no_grad():
+            model.W.add_(1.0)
+    dp = DataParallel(model, mode=mode, scale_grad_fn=_oracle_scale_grad)
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(8, 12, generator=g)
+    Y = torch.randn(8, 5, generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    dp.zero_grad()
+    loss = ((dp(xs) - ys) ** 2).sum() / 8.0        # global-batch mean, local shard contribution * world below
+    (loss * world).backward()                       # so that the rank-mean of gradients equals the global gradient
+    dp.sync_gradients()
+    res = {n: p.grad.clone() for n, p in model.named_parameters()}
+    res["W_param"] = model.W.detach().clone()
+    torch.save(res, os.path.join(out_dir, f"rank{rank}_{mode}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["A", "B"])
+def test_data_parallel_two_ranks(tmp_path, mode):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / f"rank0_{mode}.pt")
+    r1 = torch.load(tmp_path / f"rank1_{mode}.pt")
+    assert torch.equal(r0["W_param"], r1["W_param"])                 # broadcast happened
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), f"{k} differs across ranks ({mode})"
+
+    # single-process reference on the full batch
+    sys.path.insert(0, ROOT)
+    lam = 2e-2
+    model = _FakeLayer(lam)
+    g = torch.Generator().manual_seed(123)
+    X = torch.randn(8, 12, generator=g)
+    Y = torch.randn(8, 5, generator=g)
+    (((model(X) - Y) ** 2).sum() / 8.0).backward()
+    np.testing.assert_allclose(r0["W"].numpy(), model.W.grad.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r0["b"].numpy(), model.b.grad.numpy(), rtol=1e-5, atol=1e-7)
+    if mode == "B":
+        # exact mode: ds equals the single-device global-batch scale gradient
+        np.testing.assert_allclose(r0["nested_q_w_layer.scale"].numpy(), model.nested_q_w_layer.scale.grad.numpy(), rtol=1e-5)
+        np.testing.assert_allclose(r0["nested_q_b_layer.scale"].numpy(), model.nested_q_b_layer.scale.grad.numpy(), rtol=1e-5)
+    else:
+        # mode A: mean over ranks of the local scale gradients (non-linear in dy -> generally != global)
+        from oracle import lq_oracle as O
+        locals_ = []
+        for r in range(2):
+            m = _FakeLayer(lam)
+            xs, ys = X[r * 4:(r + 1) * 4], Y[r * 4:(r + 1) * 4]
+            ((((m(xs) - ys) ** 2).sum() / 8.0) * 2).backward()
+            locals_.append(m.nested_q_w_layer.scale.grad.numpy())
+        np.testing.assert_allclose(r0["nested_q_w_layer.scale"].numpy(), (locals_[0] + locals_[1]) / 2, rtol=1e-5)
+
+
+def test_grad_bucket_single_process():
+    sys.path.insert(0, ROOT)
+    from learned_quantization_amd.ddp import GradBucket
+    ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))]
+    b = GradBucket(ps)
+    assert b.flat.numel() == 17
+    (ps[0].sum() * 2 + ps[1].sum() * 3).backward()
+    assert torch.all(b.flat[:12] == 2) and torch.all(b.flat[12:] == 3)       # autograd accumulated into the bucket
+    ps[1].grad = torch.full((5,), 7.0)                                         # someone re-allocated a grad
+    b.gather_()
+    assert torch.all(b.flat[12:] == 7) and ps[1].grad.data_ptr() == b.views[1].data_ptr()
+    b.zero_()
+    assert torch.count_nonzero(b.flat) == 0

@@ -1,0 +1,181 @@
+"""GPU tests of the host surface: autograd ops, layers, loss terms, scale optimizer -- against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lq_oracle as O
+from oracle import lq_oracle_torch as OT
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_autograd_nq_op(dev):
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(0)
+    P = rng.normal(0, 0.05, size=(3, 3, 8, 16)).astype(np.float32)
+    s = rng.uniform(1e-3, 1e-2, size=(1, 1, 8, 1)).astype(np.float32)
+    w = rng.normal(0, 1e-3, size=P.shape).astype(np.float32)
+    Pt = torch.tensor(P, device=dev, requires_grad=True)
+    st = torch.tensor(s, device=dev, requires_grad=True)
+    out = lq.my_custom_gradient(Pt, st, 1e-3)
+    (out * torch.tensor(w, device=dev)).sum().backward()
+    _, ds_o = O.nq_backward(P, s, 1e-3, w)
+    assert torch.equal(Pt.grad.cpu(), torch.tensor(w))                 # dP == dy bit for bit (STE)
+    np.testing.assert_allclose(st.grad.cpu().numpy(), ds_o, rtol=RTOL)
+    # STE-only variant: ds == 0
+    Pt.grad = None
+    st.grad = None
+    out = lq.my_custom_gradient(Pt, st)
+    (out * torch.tensor(w, device=dev)).sum().backward()
+    assert torch.equal(Pt.grad.cpu(), torch.tensor(w))
+    assert torch.count_nonzero(st.grad) == 0 and st.grad.shape == st.shape
+
+
+def test_dense_layer_forward_backward(dev):
+    import learned_quantization_amd as lq
+    lq.reset_layer_names()
+    layer = lq.CustomDenseLayer(seed=42, units=10, penalty_threshold=1e-3, orientation="rowwise",
+                                initializer=lq.RandomNormal(seed=42), name="custom_dense_layer",
+                                regularizer=None, input_shape=(None, 20), device=dev)
+    assert layer.name == "custom_dense_layer" and tuple(layer.W.shape) == (20, 10)
+    assert tuple(layer.nested_q_w_layer.scale.shape) == (20, 1) and tuple(layer.nested_q_b_layer.scale.shape) == (1,)
+    with torch.no_grad():
+        layer.nested_q_w_layer.scale.fill_(0.01)
+        layer.nested_q_b_layer.scale.fill_(0.02)
+    x = torch.randn(7, 20, device=dev)
+    y = layer(x)
+    W, b = layer.W.detach().cpu().numpy(), layer.b.detach().cpu().numpy()
+    _, qW = O.fq_forward(W, np.full((20, 1), 0.01, np.float32))
+    _, qb = O.fq_forward(b, np.full((1,), 0.02, np.float32))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), x.cpu().numpy() @ qW + qb, rtol=1e-4, atol=1e-5)
+    y.square().sum().backward()
+    dW = layer.W.grad.cpu().numpy()
+    _, ds_o = O.nq_backward(W, np.full((20, 1), 0.01, np.float32), 1e-3, dW)
+    np.testing.assert_allclose(layer.nested_q_w_layer.scale.grad.cpu().numpy(), ds_o, rtol=RTOL)
+    _, dsb_o = O.nq_backward(b, np.full((1,), 0.02, np.float32), 1e-3, layer.b.grad.cpu().numpy())
+    np.testing.assert_allclose(layer.nested_q_b_layer.scale.grad.cpu().numpy(), dsb_o, rtol=RTOL)
+
+
+@pytest.mark.parametrize("padding,strides", [("same", (1, 1)), ("valid", (1, 1)), ("same", (2, 2))])
+def test_conv_layer_matches_reference_layout(dev, padding, strides):
+    import learned_quantization_amd as lq
+    lq.reset_layer_names()
+    layer = lq.CustomConv2DLayer(seed=1, penalty_threshold=1e-11, orientation="channelwise",
+                                 initializer=lq.RandomNormal(seed=1), filters=6, kernel_size=(3, 3), strides=strides,
+                                 padding=padding, name="x", regularizer=lq.l2(1e-4), input_shape=4, device=dev)
+    assert layer.name == "custom_conv2d_layer" and layer.padding == padding.upper()
+    assert tuple(layer.kernel.shape) == (3, 3, 4, 6) and tuple(layer.nested_q_k_layer.scale.shape) == (1, 1, 4, 1)
+    with torch.no_grad():
+        layer.nested_q_k_layer.scale.fill_(0.004)
+        layer.nested_q_b_layer.scale.fill_(0.003)
+    x = torch.randn(2, 4, 9, 9, device=dev)
+    y = layer(x)
+    k, b = layer.kernel.detach().cpu().numpy(), layer.b.detach().cpu().numpy()
+    _, qk = O.fq_forward(k, np.full((1, 1, 4, 1), 0.004, np.float32))
+    _, qb = O.fq_forward(b, np.full((1,), 0.003, np.float32))
+    # TF-semantics reference conv on CPU (explicit SAME padding)
+    xt = x.cpu()
+    wt = torch.tensor(qk).permute(3, 2, 0, 1)
+    if padding == "same":
+        import math
+        pads = []
+        for n, kk, ss in ((9, 3, strides[0]), (9, 3, strides[1])):
+            tot = max((math.ceil(n / ss) - 1) * ss + kk - n, 0)
+            pads.append((tot // 2, tot - tot // 2))
+        xt = torch.nn.functional.pad(xt, (pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+    ref = torch.nn.functional.conv2d(xt, wt, None, strides) + torch.tensor(qb).view(1, -1, 1, 1)
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+    y.sum().backward()
+    _, ds_o = O.nq_backward(k, np.full((1, 1, 4, 1), 0.004, np.float32), 1e-11, layer.kernel.grad.cpu().numpy())
+    np.testing.assert_allclose(layer.nested_q_k_layer.scale.grad.cpu().numpy(), ds_o, rtol=RTOL)
+    assert layer.regularization_loss() is not None
+
+
+def _mk_layers(dev, orient="channelwise"):
+    import learned_quantization_amd as lq
+    from learned_quantization_amd.custom_loss_terms import custom_layers as CL
+    lq.reset_layer_names()
+    layers = []
+    for ci, co in ((3, 8), (8, 16)):
+        l = CL.CustomConv2DLayer(seed=0, penalty_rate=1e-7, orientation=orient, initializer=lq.RandomNormal(seed=ci),
+                                 filters=co, kernel_size=(3, 3), strides=(1, 1), padding="same", name="c",
+                                 regularizer=None, input_shape=ci, device=dev)
+        with torch.no_grad():
+            l.nested_q_k_layer.scale.uniform_(1e-3, 1e-2)
+            l.nested_q_b_layer.scale.uniform_(1e-3, 1e-2)
+        layers.append(l)
+    return layers
+
+
+@pytest.mark.parametrize("orient", ["rowwise", "columnwise", "channelwise", "scalar"])
+@pytest.mark.parametrize("kind", ["maxbin", "difference", "inverse"])
+def test_loss_terms_value_and_gradients(dev, kind, orient):
+    import learned_quantization_amd as lq
+    layers = _mk_layers(dev, orient)
+    cls = {"maxbin": lq.SCCEMaxBin, "difference": lq.SCCEDifference, "inverse": lq.SCCEInverse}[kind]
+    import tempfile
+    loss_obj = cls(layers, penalty_rate=0.5, log_dir=tempfile.mkdtemp())
+    pen = getattr(loss_obj, f"compute_{kind}_penalty")()
+    np_layers = [(l.kernel.detach().cpu().numpy(), l.nested_q_k_layer.scale.detach().cpu().numpy(),
+                  l.b.detach().cpu().numpy(), l.nested_q_b_layer.scale.detach().cpu().numpy()) for l in layers]
+    oracle_fn = {"maxbin": O.maxbin_penalty, "difference": O.difference_penalty, "inverse": O.inverse_penalty}[kind]
+    assert float(pen) == pytest.approx(float(oracle_fn(np_layers)), rel=RTOL)
+    # total loss + gradients against torch-CPU autograd of the op-for-op restatement
+    y_true = torch.tensor([1, 0, 3], device=dev)
+    y_pred = torch.softmax(torch.randn(3, 5, device=dev), dim=1)
+    total = loss_obj.compute_total_loss(y_true, y_pred)
+    assert total.shape == (3,)
+    np.testing.assert_allclose(total.detach().cpu().numpy(),
+                               O.total_loss(y_true.cpu().numpy(), y_pred.cpu().numpy(), 0.5, oracle_fn(np_layers)),
+                               rtol=RTOL)
+    total.mean().backward()
+    tl = [tuple(torch.tensor(a, requires_grad=True) for a in l) for l in np_layers]
+    fn_t = {"maxbin": OT.maxbin_penalty, "difference": OT.difference_penalty, "inverse": OT.inverse_penalty}[kind]
+    (0.5 * fn_t(tl)).backward()
+    for l, (k, ks, b, bs) in zip(layers, tl):
+        for got, want, nm in ((l.nested_q_k_layer.scale.grad, ks.grad, "ds_k"), (l.nested_q_b_layer.scale.grad, bs.grad, "ds_b")):
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-7, err_msg=f"{kind} {orient} {nm}")
+        if kind != "inverse":
+            np.testing.assert_allclose(l.kernel.grad.cpu().numpy(), k.grad.numpy(), rtol=1e-4, atol=1e-9, err_msg=f"{kind} {orient} dK")
+            np.testing.assert_allclose(l.b.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-9, err_msg=f"{kind} {orient} db")
+
+
+def test_scale_adam_matches_keras_restatement(dev):
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(0)
+    s0 = np.full(64, O.SCALE_INIT, np.float32)
+    p = torch.nn.Parameter(torch.tensor(s0, device=dev))
+    p.lq_constraint = lq.MinValueConstraint(lq.SCALE_INIT)
+    opt = lq.ScaleAdam([p], lr=1e-4)
+    s, m, v = s0.copy(), np.zeros(64, np.float32), np.zeros(64, np.float32)
+    for step in range(1, 6):
+        g = rng.normal(0, 1.0, size=64).astype(np.float32) * (10.0 ** rng.integers(-6, 1))
+        p.grad = torch.tensor(g, device=dev)
+        opt.step()
+        s, m, v = O.keras_adam_step(s, g, m, v, step, lr=1e-4, min_value=O.SCALE_MIN)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), s, rtol=2e-6, atol=0)
+        assert float(p.min()) >= O.SCALE_MIN
+    # bare constraint
+    c = lq.MinValueConstraint(0.5)
+    w = torch.tensor([0.1, 0.5, 0.9, float("nan")], device=dev)
+    got = c(w).cpu().numpy()
+    np.testing.assert_array_equal(got[:3], np.array([0.5, 0.5, 0.9], np.float32))
+    assert np.isnan(got[3]) and c.get_config() == {"min_value": 0.5}
+
+
+def test_callback_statistic_absmax_over_axis(dev):
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(0)
+    k = rng.normal(0, 0.05, size=(3, 3, 8, 16)).astype(np.float32)
+    s = rng.uniform(1e-3, 1e-2, size=(1, 1, 8, 1)).astype(np.float32)
+    got = lq.q_absmax_over_axis(torch.tensor(k, device=dev), torch.tensor(s, device=dev), axis=1).cpu().numpy()
+    want = np.max(np.abs(O.quantized_integers(k, s)), axis=1)     # custom_callbacks.py:98
+    np.testing.assert_array_equal(got, want)

@@ -1,0 +1,234 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of include/lq_hip.h) against the CPU oracle.
+
+Bars (north_star): integer q and the dequantized product out = q*s bit-exact; max|q| bit-exact;
+tanh/mean-derived quantities (ds, penalties) within rtol 1e-5.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import learned_quantization_amd._hip as _hip
+    _hip.load()   # fail loudly if the extension is missing
+    return torch.device("cuda:0")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _check_case(P, s, dy, lam, dev, name=""):
+    import learned_quantization_amd as lq
+    q_o, out_o = O.fq_forward(P, s)
+    _, ds_o, im = O.nq_backward(P, s, lam, dy, return_intermediates=True)
+    Pt, st, dyt = _t(P, dev), _t(s, dev), _t(dy, dev)
+    out, q = lq.fq_forward(Pt, st, q_dtype=torch.float32)
+    np.testing.assert_array_equal(q.cpu().numpy(), q_o, err_msg=f"{name}: q")
+    np.testing.assert_array_equal(out.cpu().numpy(), out_o, err_msg=f"{name}: out")
+    ds, parts = lq.fq_scale_grad(Pt, st, dyt, lam, return_parts=True)
+    parts = parts.cpu().numpy()
+    np.testing.assert_array_equal(parts[0], np.asarray(im["maxvalue"], np.float32).reshape(-1), err_msg=f"{name}: max|q|")
+    np.testing.assert_allclose(parts[1], np.asarray(im["mean"], np.float32).reshape(-1), rtol=RTOL, atol=1e-30,
+                               equal_nan=True, err_msg=f"{name}: mean")
+    assert ds.shape == st.shape
+    np.testing.assert_allclose(ds.cpu().numpy(), ds_o, rtol=RTOL, atol=1e-30, equal_nan=True, err_msg=f"{name}: ds")
+    # fused single-pass kernel gives the same out (bit-exact) and ds
+    out2, ds2 = lq.fq_fwd_bwd_fused(Pt, st, dyt, lam)
+    np.testing.assert_array_equal(out2.cpu().numpy(), out_o, err_msg=f"{name}: fused out")
+    np.testing.assert_array_equal(ds2.cpu().numpy(), ds.cpu().numpy(), err_msg=f"{name}: fused ds == unfused ds")
+
+
+def test_kat_on_gpu(kat, dev):
+    P, s, dy = (np.array(kat[k], np.float32) for k in ("P", "s", "dy"))
+    import learned_quantization_amd as lq
+    out, q = lq.fq_forward(_t(P, dev), _t(s, dev), q_dtype=torch.float32)
+    np.testing.assert_array_equal(q.cpu().numpy(), np.array(kat["q"], np.float32))
+    np.testing.assert_array_equal(out.cpu().numpy(), np.array(kat["out"], np.float32))
+    for lam in ("0.5", "0.05"):
+        ds = lq.fq_scale_grad(_t(P, dev), _t(s, dev), _t(dy, dev), float(lam))
+        np.testing.assert_allclose(ds.cpu().numpy(), np.array(kat[f"lambda_{lam}"]["ds"], np.float32), rtol=1e-6)
+
+
+def test_golden_cases_on_gpu(golden_cases, dev):
+    for name, c in golden_cases.items():
+        _check_case(c["P"], c["s"], c["dy"], float(c["lam"]), dev, name)
+        import learned_quantization_amd as lq
+        out, q = lq.fq_forward(_t(c["P"], dev), _t(c["s"], dev), q_dtype=torch.float32)
+        np.testing.assert_array_equal(q.cpu().numpy(), c["q"], err_msg=name)       # committed fixture, not live oracle
+        np.testing.assert_array_equal(out.cpu().numpy(), c["out"], err_msg=name)
+
+
+# every traversal mode of the kernels: row-big (vector + scalar), row-small (all team widths), column
+SHAPES = [
+    ((784, 128), "rowwise"), ((784, 128), "columnwise"), ((784, 128), "channelwise"), ((784, 128), "scalar"),
+    ((128, 10), "rowwise"), ((128, 10), "columnwise"), ((10,), "scalar"), ((128,), "scalar"),
+    ((3, 3, 3, 32), "rowwise"), ((3, 3, 3, 32), "columnwise"), ((3, 3, 3, 32), "channelwise"), ((3, 3, 3, 32), "scalar"),
+    ((3, 3, 64, 128), "rowwise"), ((3, 3, 64, 128), "columnwise"), ((3, 3, 64, 128), "channelwise"),
+    ((7, 7, 3, 64), "channelwise"), ((1, 1, 64, 128), "channelwise"), ((1, 1, 64, 128), "rowwise"),
+    ((5, 1031), "rowwise"),            # L >= 1024 and L % 4 != 0 -> scalar row-big path
+    ((3, 4100), "rowwise"),            # L % 4 == 0 -> vector path with a partial chunk
+    ((2, 3, 9000), "columnwise"),      # several chunks per row
+    ((100003,), "scalar"),             # flat, ragged tail on the vector path
+    ((33, 5, 3), "columnwise"),        # inner = 3 < 16, outer > 1 -> column mode
+    ((1000, 7, 2), "columnwise"),      # column mode with row slices
+    ((50, 9), "rowwise"),              # tiny rows (lanes-per-row = 4)
+    ((6, 1), "rowwise"),               # L = 1
+    ((4, 3, 16, 16), "columnwise"),    # NCHW per-channel, small
+]
+
+
+@pytest.mark.parametrize("shape,orient", SHAPES)
+def test_random_parity_all_modes(shape, orient, dev):
+    rng = np.random.default_rng(abs(hash((shape, orient))) % (2 ** 32))
+    for lam in (0.0, 1e-10, 3e-2):
+        P = rng.normal(0, 0.05, size=shape).astype(np.float32)
+        dy = rng.normal(0, 1e-3, size=shape).astype(np.float32)
+        s = rng.uniform(1e-3, 3e-2, size=O.scale_shape(shape, orient)).astype(np.float32)
+        _check_case(P, s, dy, lam, dev, f"{shape} {orient} lam={lam}")
+
+
+def test_init_scale_large_integers(dev):
+    """s = 100*eps: |q| ~ 2e4, the regime where reciprocal-multiply differs (SURVEY section 7 hard part 1)."""
+    rng = np.random.default_rng(1)
+    P = rng.normal(0, 0.05, size=(1 << 22,)).astype(np.float32)
+    s = np.array([O.SCALE_INIT], np.float32)
+    import learned_quantization_amd as lq
+    q = lq.quantized_integers(_t(P, dev), _t(s, dev), torch.int32).cpu().numpy()
+    q_o = O.quantized_integers(P, s).astype(np.int32)
+    np.testing.assert_array_equal(q, q_o)
+    assert np.count_nonzero(q_o != np.floor(P * (np.float32(1) / s[0]))) > 0   # the trap is real on this data
+    for sv in (1e-4, 3.3e-3, 0.77):
+        s = np.array([sv], np.float32)
+        np.testing.assert_array_equal(lq.quantized_integers(_t(P, dev), _t(s, dev), torch.int32).cpu().numpy(),
+                                      O.quantized_integers(P, s).astype(np.int32))
+
+
+def test_mnist_real_weights_on_gpu(mnist_weights, mnist_expected, dev):
+    import learned_quantization_amd as lq
+    meta, exp = mnist_expected
+    for name in ("W1", "b1", "W2", "b2"):
+        P = mnist_weights[name]
+        q = lq.quantized_integers(_t(P, dev), _t(np.array([O.SCALE_INIT], np.float32), dev), torch.int32).cpu().numpy()
+        np.testing.assert_array_equal(q, exp[f"{name}_q_init"].astype(np.int32))
+        for key, m in meta.items():
+            if not key.startswith(name + "@"):
+                continue
+            tag = key.split("@")[1]
+            if tag.endswith("absmax12"):
+                orient = tag.split("_")[0]
+                sshape = O.scale_shape(P.shape, orient)
+                s = (np.abs(P).max(axis=1 if orient == "rowwise" else 0).reshape(sshape) / 12.0 + 1e-6).astype(np.float32)
+            else:
+                s = np.array([np.float32(float(tag))], np.float32)
+            q = lq.quantized_integers(_t(P, dev), _t(s, dev), torch.int32).cpu().numpy()
+            assert hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest() == m["sha256"], key
+
+
+def test_q_dtypes_and_int8_wrap(dev):
+    import learned_quantization_amd as lq
+    P = np.array([0.0, 1.0, 127.0, 128.0, 255.0, 256.0, -1.0, -128.0, -129.0, 300.7, -0.3], np.float32)
+    s = np.array([1.0], np.float32)
+    q8 = lq.quantized_integers(_t(P, dev), _t(s, dev), torch.int8).cpu().numpy()
+    np.testing.assert_array_equal(q8, O.export_int8(P, s))
+    q32 = lq.quantized_integers(_t(P, dev), _t(s, dev), torch.int32).cpu().numpy()
+    np.testing.assert_array_equal(q32, np.floor(P).astype(np.int32))
+
+
+def test_edge_empty_and_bad_arguments(dev):
+    import learned_quantization_amd as lq
+    from learned_quantization_amd._hip import LQError
+    with pytest.raises(ValueError):
+        lq.fq_forward(torch.empty(0, device=dev), torch.ones(1, device=dev))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lq.fq_forward(torch.ones(4), torch.ones(1))
+    with pytest.raises(TypeError):
+        lq.fq_forward(torch.ones(4, device=dev, dtype=torch.float64), torch.ones(1, device=dev))
+    with pytest.raises(ValueError):
+        lq.fq_forward(torch.ones(4, 4, device=dev), torch.ones(2, 2, device=dev))
+    # non-contiguous inputs are accepted (made contiguous)
+    P = torch.randn(16, 8, device=dev).t()
+    s = torch.full((8, 1), 0.1, device=dev)
+    out = lq.fq_forward(P, s)
+    q_o, out_o = O.fq_forward(P.cpu().numpy(), s.cpu().numpy())
+    np.testing.assert_array_equal(out.cpu().numpy(), out_o)
+    # misaligned base pointer (offset by one float) still correct: falls to the scalar kernels
+    base = torch.randn(4097 * 3 + 1, device=dev)
+    Pm = base[1:].view(3, 4097)
+    sm = torch.tensor([[0.01], [0.02], [0.03]], device=dev)
+    _, out_o = O.fq_forward(Pm.cpu().numpy(), sm.cpu().numpy())
+    np.testing.assert_array_equal(lq.fq_forward(Pm, sm).cpu().numpy(), out_o)
+
+
+def test_nan_and_inf_inputs(dev):
+    import learned_quantization_amd as lq
+    P = np.array([[0.1, np.nan, 0.3, -0.2], [np.inf, 0.2, -0.1, 0.05]], np.float32)
+    dy = np.array([[1e-3, 1e-3, np.nan, 1e-4], [1e-3, 2e-3, 1e-3, 1e-3]], np.float32)
+    s = np.array([[0.01], [0.02]], np.float32)
+    q_o, out_o = O.fq_forward(P, s)
+    out, q = lq.fq_forward(_t(P, dev), _t(s, dev), q_dtype=torch.float32)
+    np.testing.assert_array_equal(q.cpu().numpy(), q_o)
+    np.testing.assert_array_equal(out.cpu().numpy(), out_o)
+    _, ds_o = O.nq_backward(P, s, 1e-2, dy)
+    ds = lq.fq_scale_grad(_t(P, dev), _t(s, dev), _t(dy, dev), 1e-2).cpu().numpy()
+    assert np.array_equal(np.isnan(ds), np.isnan(ds_o))
+
+
+def test_determinism_bitwise(dev):
+    import learned_quantization_amd as lq
+    g = torch.Generator(device="cpu").manual_seed(0)
+    P = torch.randn(64, 3, 56, 56, generator=g).mul_(50).to(dev)
+    dy = torch.randn(64, 3, 56, 56, generator=g).mul_(1e-3).to(dev)
+    s = torch.tensor([0.5, 1.0, 2.0], device=dev).view(1, 3, 1, 1)
+    ref = lq.fq_scale_grad(P, s, dy, 1e-3)
+    for _ in range(5):
+        assert torch.equal(lq.fq_scale_grad(P, s, dy, 1e-3), ref)
+
+
+def test_bench_shape_full_size_properties(dev):
+    """BASELINE workload 256x3x224x224 (154 MB): too big for the NumPy oracle to be quick on every
+    element-wise check, so: (1) exact identities on the device, (2) oracle on a strided sample of
+    whole (n, c) planes, (3) ds against the oracle's per-plane pieces merged on the host."""
+    import learned_quantization_amd as lq
+    torch.manual_seed(42)
+    x = torch.rand(256, 3, 224, 224, device=dev) * 255.0
+    dy = torch.randn(256, 3, 224, 224, device=dev) * 1e-3
+    s = torch.tensor([0.5, 1.0, 2.0], device=dev).view(1, 3, 1, 1)
+    out, q = lq.fq_forward(x, s, q_dtype=torch.float32)
+    assert torch.equal(q, torch.floor(q))                              # integers
+    assert torch.equal(out, q * s)                                     # out == q*s exactly
+    assert bool(((x - out) >= 0).all()) and bool(((x - out) < s).all())   # floor: 0 <= x - out < s
+    assert torch.equal(lq.fq_forward(out, s), out)                     # idempotent on its own output (s = 2^k)
+    # oracle on sampled planes
+    xs, qs, outs = x[::37].cpu().numpy(), q[::37].cpu().numpy(), out[::37].cpu().numpy()
+    q_o, out_o = O.fq_forward(xs, s.cpu().numpy())
+    np.testing.assert_array_equal(qs, q_o)
+    np.testing.assert_array_equal(outs, out_o)
+    for lam in (0.0, 1e-11, 1e-3):
+        ds, parts = lq.fq_scale_grad(x, s, dy, lam, return_parts=True)
+        out2, ds2 = lq.fq_fwd_bwd_fused(x, s, dy, lam)
+        assert torch.equal(out2, out) and torch.equal(ds2, ds)
+        # full oracle in float32 NumPy, channel by channel (a few seconds)
+        xn, dyn = x.cpu().numpy(), dy.cpu().numpy()
+        _, ds_o, im = O.nq_backward(xn, s.cpu().numpy(), lam, dyn, return_intermediates=True)
+        np.testing.assert_array_equal(parts[0].cpu().numpy(), im["maxvalue"].reshape(-1))
+        np.testing.assert_allclose(ds.cpu().numpy(), ds_o, rtol=RTOL, atol=1e-30)
+    # per-tensor scale variant
+    s1 = torch.tensor([1.0], device=dev)
+    ds = lq.fq_scale_grad(x, s1, dy, 1e-3)
+    _, ds_o = O.nq_backward(x.cpu().numpy(), s1.cpu().numpy(), 1e-3, dy.cpu().numpy())
+    np.testing.assert_allclose(ds.cpu().numpy(), ds_o, rtol=RTOL)
+    # linearity-type property: scaling dy and lambda by the same factor leaves the below-count unchanged
+    _, p1 = lq.fq_scale_grad(x, s, dy, 1e-3, return_parts=True)
+    _, p2 = lq.fq_scale_grad(x, s, dy * 4.0, 4e-3, return_parts=True)
+    assert torch.equal(p1[2], p2[2]) and torch.equal(p1[0], p2[0])

@@ -1,0 +1,172 @@
+"""CPU tests of the host logic and of the C-ABI library surface (no compute launches: no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import learned_quantization_amd as lq
+from learned_quantization_amd import _hip
+from oracle import lq_oracle as O
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _hip.load()
+    header = open(os.path.join(ROOT, "include", "lq_hip.h")).read()
+    declared = set(re.findall(r"\b(lq_[a-z0-9_]+)\s*\(", header))
+    declared -= {"lq_status", "lq_qdtype", "lq_adam_mode"}
+    assert len(declared) >= 16
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/lq_hip.h but not exported"
+    assert declared == set(_hip.SIGNATURES), "python binding table and header disagree"
+    assert lib.lq_version() == 1
+    assert lib.lq_status_string(-3) == b"LQ_EWORKSPACE"
+
+
+def test_argument_validation_without_gpu():
+    """Every entry point validates before touching the device: bad calls return an error code, no launch."""
+    lib = _hip.load()
+    assert lib.lq_fq_forward(None, None, None, None, 0, 1, 1, 1, None) == -1
+    assert b"NULL" in lib.lq_last_error()
+    assert lib.lq_fq_forward(None, None, None, None, 0, 0, 1, 1, None) == -1
+    assert b"positive" in lib.lq_last_error()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    assert lib.lq_fq_forward(p, p, None, None, 0, 1, 1, 16, None) == -1             # neither out nor q
+    assert lib.lq_fq_forward(p, p, p, p, 9, 1, 1, 16, None) == -1                    # bad q_dtype
+    assert lib.lq_fq_forward(p + 2, p, p, None, 0, 1, 1, 16, None) == -4             # misaligned
+    assert lib.lq_fq_scale_grad(p, p, p, 0.0, p, None, None, 0, 1, 1, 16, None) == -3   # no workspace
+    assert lib.lq_fq_scale_grad(p, p, p, 0.0, p, None, p, 8, 1, 1, 16, None) == -3      # workspace too small
+    assert b"too small" in lib.lq_last_error()
+    assert lib.lq_scale_adam_step(p, p, p, p, 4, 1e-4, 0.9, 0.999, 1e-7, 0, 0.0, 0, None) == -1   # step is 1-based
+    assert lib.lq_q_absmax_over_axis(p, p, p, 2, 2, 2, 1, 1, 16, None) == -1         # geometry mismatch
+    assert lib.lq_workspace_bytes(0, 1, 1) == 0
+
+
+@pytest.mark.parametrize("desc", [(256, 3, 50176), (1, 1, 38535168), (1, 784, 128), (784, 128, 1), (9, 64, 128),
+                                  (1, 3, 3 * 512 * 512), (1, 1, 10), (1000, 7, 2), (1, 1000000, 10)])
+def test_workspace_is_small_relative_to_tensor(desc):
+    lib = _hip.load()
+    n = desc[0] * desc[1] * desc[2]
+    ws = lib.lq_workspace_bytes(*desc)
+    assert ws >= 256 and ws % 4 == 0
+    if n >= 1 << 16:
+        assert ws <= n * 4, f"workspace {ws} B for {n} elements"
+
+
+def test_descriptor_and_scale_shape_agree_with_oracle():
+    for shape in [(784, 128), (128, 10), (3, 3, 64, 128), (7, 7, 3, 64), (10,), (256, 3, 224, 224)]:
+        for orient in lq.ORIENTATIONS:
+            if len(shape) == 1 and orient != "scalar":
+                continue
+            ss = lq.scale_shape(shape, orient)
+            assert ss == O.scale_shape(shape, orient)
+            assert lq.group_descriptor(shape, ss) == O.group_descriptor(shape, ss)
+    with pytest.raises(ValueError, match="Invalid scaler application: diagonal"):
+        lq.scale_shape((3, 3), "diagonal")
+    with pytest.raises(ValueError):
+        lq.group_descriptor((4, 4), (2, 2))
+    with pytest.raises(ValueError):
+        lq.group_descriptor((4, 4), (3, 1))
+    with pytest.raises(ValueError):
+        lq.group_descriptor((0, 4), (1,))
+
+
+def test_descriptor_is_the_flat_index_rule():
+    rng = np.random.default_rng(0)
+    for shape, orient in [((5, 7), "rowwise"), ((5, 7), "columnwise"), ((2, 3, 4, 5), "channelwise"), ((2, 3, 4, 5), "columnwise")]:
+        s = rng.uniform(1, 2, size=lq.scale_shape(shape, orient)).astype(np.float32)
+        outer, G, inner = lq.group_descriptor(shape, s.shape)
+        full = np.broadcast_to(s, shape).reshape(-1)
+        i = np.arange(full.size)
+        np.testing.assert_array_equal(full, s.reshape(-1)[(i // inner) % G])
+
+
+def test_layers_construct_on_cpu_and_fail_loudly_on_call():
+    lq.reset_layer_names()
+    d1 = lq.CustomDenseLayer(seed=42, units=128, penalty_threshold=1e-10, orientation="rowwise",
+                             initializer=lq.RandomNormal(seed=42), name="ignored", regularizer=None, input_shape=784)
+    d2 = lq.CustomDenseLayer(seed=42, units=10, penalty_threshold=1e-10, orientation="columnwise",
+                             initializer=lq.RandomNormal(seed=42), name="ignored", regularizer=None, input_shape=128)
+    assert (d1.name, d2.name) == ("custom_dense_layer", "custom_dense_layer_1")     # Keras auto-names
+    assert tuple(d1.W.shape) == (784, 128) and tuple(d1.b.shape) == (128,)
+    assert tuple(d1.nested_q_w_layer.scale.shape) == (784, 1)
+    assert tuple(d2.nested_q_w_layer.scale.shape) == (1, 10)
+    assert tuple(d1.nested_q_b_layer.scale.shape) == (1,) and d1.nested_q_b_layer.orientation == "scalar"
+    assert float(d1.nested_q_w_layer.scale[0, 0]) == np.float32(np.finfo(np.float32).eps * 100)
+    assert abs(float(d1.W.std()) - 0.05) < 0.005                                     # RandomNormal stddev 0.05
+    c = lq.CustomConv2DLayer(seed=1, penalty_threshold=1e-11, orientation="channelwise", initializer=lq.RandomNormal(seed=1),
+                             filters=32, kernel_size=(3, 3), strides=(1, 1), padding="same", name="n",
+                             regularizer=lq.l2(1e-4), input_shape=3)
+    assert c.name == "custom_conv2d_layer" and c.padding == "SAME"
+    assert tuple(c.kernel.shape) == (3, 3, 3, 32) and tuple(c.nested_q_k_layer.scale.shape) == (1, 1, 3, 1)
+    nb = lq.CustomConv2DLayerNoBias(seed=1, penalty_threshold=None, orientation="scalar", initializer=lq.RandomNormal(seed=1),
+                                    filters=4, kernel_size=(1, 1), strides=(1, 1), padding="valid", name="n",
+                                    regularizer=None, input_shape=3)
+    assert not hasattr(nb, "b") and not hasattr(nb, "nested_q_b_layer")
+    assert len(lq.scale_parameters(torch.nn.ModuleList([d1, d2, c, nb]))) == 7
+    with pytest.raises(ValueError, match="Invalid scaler application"):
+        lq.CustomQuantizedScaleLayer(1e-3, None, "diagonal").build((3, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        d1(torch.zeros(2, 784))                                                      # product path never falls back
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lq.my_custom_gradient(torch.zeros(4), torch.ones(1), 1e-3)
+
+
+def test_trained_weights_initialisation(mnist_weights):
+    lq.reset_layer_names()
+    d = lq.CustomDenseLayer(seed=0, units=128, penalty_threshold=1e-10, orientation="scalar", initializer=None, name="n",
+                            regularizer=None, trained_weights=[mnist_weights["W1"], mnist_weights["b1"]], input_shape=784)
+    np.testing.assert_array_equal(d.W.detach().numpy(), mnist_weights["W1"])
+    np.testing.assert_array_equal(d.b.detach().numpy(), mnist_weights["b1"])
+    with pytest.raises(ValueError):
+        lq.CustomDenseLayer(seed=0, units=7, penalty_threshold=1e-10, orientation="scalar", initializer=None, name="n",
+                            regularizer=None, trained_weights=[mnist_weights["W1"], mnist_weights["b1"]], input_shape=784)
+
+
+def test_reference_import_paths_exist():
+    from learned_quantization_amd.nested_quantization_layer import custom_layers as NQ
+    from learned_quantization_amd.custom_loss_terms import custom_layers as CL
+    from learned_quantization_amd.custom_loss_terms import custom_loss_functions as CF
+    import inspect
+    assert list(inspect.signature(NQ.my_custom_gradient).parameters) == ["parameter", "scale", "penalty_threshold"]
+    assert list(inspect.signature(CL.my_custom_gradient).parameters) == ["parameter", "scale"]
+    assert list(inspect.signature(NQ.CustomQuantizedScaleLayer.__init__).parameters)[1:4] == ["penalty_threshold", "initializer", "orientation"]
+    assert list(inspect.signature(CL.CustomQuantizedScaleLayer.__init__).parameters)[1:4] == ["penalty_rate", "initializer", "orientation"]
+    assert list(inspect.signature(NQ.CustomDenseLayer.__init__).parameters)[1:9] == [
+        "seed", "units", "penalty_threshold", "orientation", "initializer", "name", "regularizer", "trained_weights"]
+    assert list(inspect.signature(NQ.CustomConv2DLayer.__init__).parameters)[1:12] == [
+        "seed", "penalty_threshold", "orientation", "initializer", "filters", "kernel_size", "strides", "padding", "name",
+        "regularizer", "trained_weights"]
+    for cls in (CF.SCCEMaxBin, CF.SCCEDifference, CF.SCCEInverse):
+        assert list(inspect.signature(cls.__init__).parameters)[1:5] == ["layers", "penalty_rate", "log_dir", "l2_lambda"]
+        assert hasattr(cls, "compute_total_loss")
+    assert hasattr(CF.SCCEMaxBin, "compute_maxbin_penalty") and hasattr(CF.SCCEDifference, "compute_difference_penalty")
+    assert hasattr(CF.SCCEInverse, "compute_inverse_penalty")
+    assert NQ.MinValueConstraint(0.5).get_config() == {"min_value": 0.5}
+
+
+def test_product_code_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under learned_quantization_amd/ may import or call it."""
+    pkg = os.path.join(ROOT, "learned_quantization_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+                assert "lq_oracle" not in src, f"{f} references the oracle"
+
+
+def test_sparse_categorical_crossentropy_matches_oracle():
+    rng = np.random.default_rng(0)
+    logits = rng.normal(size=(6, 10)).astype(np.float32)
+    p = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+    p[0, 3] = 0.0                                                   # clipped to 1e-7
+    y = np.array([3, 1, 4, 1, 5, 9])
+    got = lq.sparse_categorical_crossentropy(torch.tensor(y), torch.tensor(p)).numpy()
+    np.testing.assert_allclose(got, O.sparse_categorical_crossentropy(y, p), rtol=1e-6)
+    assert got[0] == pytest.approx(-np.log(1e-7), rel=1e-5)
