@@ -127,10 +127,12 @@ int lq_penalty_inverse_bwd(const float* s, const float* c_dev, float c_scale, fl
 /* ---- K6: scale update ---------------------------------------------------------------
  * Adam step on a scale vector fused with the projection of MinValueConstraint
  *   custom_layers.py:35-46, attached at :158,170,182,191 with min_value = 100*eps_f32:
- *   s <- max(adam(s, ds), min_value).  `step` is the 1-based iteration count.
+ *   s <- max(adam(s, ds), min_value).  `step` is the 1-based iteration count.  Hyper-parameters are
+ *   doubles because Keras/torch form (1-beta) and the bias corrections from Python doubles before
+ *   the fp32 tensor arithmetic; passing floats would change the last bits of every update.
  * lq_min_value_project is the bare constraint  w <- max(w, min_value)  (:42-43).      */
 int lq_scale_adam_step(float* s, const float* ds, float* m, float* v, int64_t n,
-                       float lr, float beta1, float beta2, float eps, int64_t step,
+                       double lr, double beta1, double beta2, double eps, int64_t step,
                        float min_value, int mode, void* stream);
 int lq_min_value_project(float* w, int64_t n, float min_value, void* stream);
 

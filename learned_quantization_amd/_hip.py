@@ -22,6 +22,7 @@ LQ_ADAM_KERAS, LQ_ADAM_TORCH = 0, 1
 
 _c_i64 = ctypes.c_int64
 _c_f = ctypes.c_float
+_c_d = ctypes.c_double
 _c_p = ctypes.c_void_p
 _c_sz = ctypes.c_size_t
 _c_int = ctypes.c_int
@@ -41,7 +42,7 @@ SIGNATURES = {
     "lq_penalty_difference_bwd": (_c_int, [_c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p, _c_sz, _c_i64, _c_i64, _c_i64, _c_p]),
     "lq_penalty_inverse_fwd": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
     "lq_penalty_inverse_bwd": (_c_int, [_c_p, _c_p, _c_f, _c_p, _c_i64, _c_p]),
-    "lq_scale_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_i64, _c_f, _c_int, _c_p]),
+    "lq_scale_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_d, _c_d, _c_d, _c_d, _c_i64, _c_f, _c_int, _c_p]),
     "lq_min_value_project": (_c_int, [_c_p, _c_i64, _c_f, _c_p]),
     "lq_q_absmax_over_axis": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
 }

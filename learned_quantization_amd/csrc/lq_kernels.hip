@@ -33,8 +33,7 @@ namespace lq {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr float kEpsF32 = 1.1920928955078125e-07f;   // np.finfo(np.float32).eps, custom_layers.py:11
-constexpr int64_t kChunkMax = 8192;                  // elements per block in the streaming kernels
-constexpr int kUnroll = 4;                           // independent 16-B loads in flight per lane and operand
+constexpr int64_t kNtBytes = 64ll << 20;             // tensors at least this large are streamed with nontemporal accesses
 
 // ------------------------------------------------------------------------------------------
 //  Parameters shared by every kernel (passed by value in the kernarg segment).
@@ -47,6 +46,7 @@ struct Params {
     void* q;             // optional integer view
     int q_dtype;
     float lam;
+    int tmode;           // 0: lambda < 4e-4 (tanh(d) == d), 1: lambda <= 0.25 (polynomial), 2: general (ocml tanhf)
     const float* mb;     // per-group max(|P|/s)      (maxbin backward)
     const uint32_t* ties;
     const float* c_dev;  // upstream gradient, device scalar
@@ -60,8 +60,12 @@ struct Params {
 // Per-group context, loaded once per row / column.
 struct Ctx {
     float s;
+    float r;      // RN(1/s)
+    int fast;     // s is inside the window where the uniform-divisor division is exact
     float k0;
     float k1;
+    float lam_hi; // RN(lambda * 1.000001): a >= lam_hi*b  =>  RN(a/b) >= lambda for sure
+    int sure_ok;  // lam_hi*b cannot underflow for any b this row can produce (b >= min(s, eps_f32))
 };
 
 // Narrow accumulator (inside streaming kernels) and wide accumulator (finalize).
@@ -85,28 +89,159 @@ enum OpKind {
     OP_QONLY = 7,      // integer view only (callbacks / export)
 };
 
-// |tanh(d)|.  For |d| < 4e-4, tanh(d) == d to fp32 precision (d^2/3 < 2^-24): the published
-// thresholds (lambda <= 1e-8) never leave this branch.  Otherwise ocml tanhf (<= 2 ulp).
-__device__ __forceinline__ float abs_tanh(float d) {
-    float a = fabsf(d);
-    if (a < 4.0e-4f) return a;
-    return tanhf(a);
+// ------------------------------------------------------------------------------------------
+//  x / s for a divisor that is uniform over the block: correctly rounded, ~8 VALU instead of the
+//  ~15-instruction v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence.
+//    r = RN(1/s);  q0 = RN(x r);  e0 = x - s q0 (exact, fma);  q1 = RN(q0 + e0 r);
+//    e1 = x - s q1 (exact);  t = RN(q1 + e1 r)
+//  By Markstein's theorem the last step rounds correctly when r is the correctly rounded
+//  reciprocal and q1 is within 1 ulp, for every s whose mantissa is not all ones.  The window
+//  (2^-40 <= s <= 2^40, 2^-80 <= |x| < 2^81) keeps every intermediate normal so that the
+//  residuals are exact; anything outside (zeros, denormals, Inf, NaN, huge, s <= 0) takes the IEEE
+//  `/`.  tests/tools/check_fast_div.c checks the sequence against `/` for all 2^23 mantissas of x
+//  per divisor; tests/test_gpu_parity.py checks the kernels bit for bit against the oracle.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void div_ctx(Ctx& c) {
+    const uint32_t sb = __float_as_uint(c.s);
+    const uint32_t ex = (sb >> 23) & 0xffu;
+    const bool ok = (sb >> 31) == 0u && ex >= 127u - 40u && ex <= 127u + 40u && (sb & 0x7fffffu) != 0x7fffffu;
+    c.r = 1.0f / c.s;
+    c.fast = ok ? 1 : 0;
 }
 
-__device__ __forceinline__ void fq_core(float x, float s, float& q, float& o) {
-    float t = x / s;      // IEEE RN fp32 division (hipcc default: correctly rounded) -- custom_layers.py:56-58
-    q = floorf(t);        // :59
-    o = q * s;            // :60
+__device__ __forceinline__ float div_by_uniform(float x, const Ctx& c) {
+    if (c.fast) {   // block/row-uniform
+        const uint32_t ex = (__float_as_uint(x) >> 23) & 0xffu;
+        if (__builtin_expect((ex - 47u) <= 160u, 1)) {
+            const float q0 = x * c.r;
+            const float e0 = __builtin_fmaf(-c.s, q0, x);
+            const float q1 = __builtin_fmaf(e0, c.r, q0);
+            const float e1 = __builtin_fmaf(-c.s, q1, x);
+            return __builtin_fmaf(e1, c.r, q1);
+        }
+        if (x == 0.0f) return x;   // (+-0) / s = +-0 for s > 0
+    }
+    return x / c.s;                // IEEE RN fp32 division (hipcc default: correctly rounded)
 }
 
-__device__ __forceinline__ void nq_accumulate(float q, float o, float dy, float lam, Acc& acc) {
-    float nz = (o == 0.0f) ? kEpsF32 : o;              // :63
-    float ratio = fabsf(dy) / fabsf(nz);               // :64
-    uint32_t aq = __float_as_uint(fabsf(q));           // :68 / :94  max|q| on the bit pattern
-    acc.a = aq > acc.a ? aq : acc.a;
+// |tanh(d)| for d = lambda - ratio, 0 < d <= lambda (or NaN).
+//   tmode 0 (lambda < 4e-4): tanh(d) == d to fp32 precision (d^2/3 < 2^-24) -- every published
+//           threshold (lambda <= 1e-8) is here;
+//   tmode 1 (lambda <= 0.25): odd minimax polynomial, < 1 ulp on [0, 0.25];
+//   tmode 2: ocml tanhf.
+template <int TM>
+__device__ __forceinline__ float abs_tanh_t(float d) {
+    const float a = fabsf(d);
+    if (TM == 0) return a;
+    if (TM == 1) {
+        const float z = a * a;
+        float p = 2.0800685256e-02f;
+        p = __builtin_fmaf(p, z, -5.3927052600e-02f);
+        p = __builtin_fmaf(p, z, 1.3333282305e-01f);
+        p = __builtin_fmaf(p, z, -3.3333333236e-01f);
+        return __builtin_fmaf(a * z, p, a);
+    }
+    return a < 4.0e-4f ? a : tanhf(a);
+}
+
+__device__ __forceinline__ float abs_tanh(float d, int tmode) {
+    if (tmode == 0) return abs_tanh_t<0>(d);
+    if (tmode == 1) return abs_tanh_t<1>(d);
+    return abs_tanh_t<2>(d);
+}
+
+__device__ __forceinline__ void fq_core(float x, const Ctx& c, float& q, float& o) {
+    const float t = div_by_uniform(x, c);   // custom_layers.py:56-58
+    q = floorf(t);                           // :59
+    o = q * c.s;                             // :60
+}
+
+__device__ __forceinline__ void nq_accumulate(float q, float o, float dy, float lam, int tmode, Acc& acc) {
+    const float nz = (o == 0.0f) ? kEpsF32 : o;        // :63
+    const float a = fabsf(dy), b = fabsf(nz);
+    acc.a = __float_as_uint(fmaxf(__uint_as_float(acc.a), fabsf(q)));   // :68 / :94
+    const float ratio = a / b;                         // :64
     if (!(ratio >= lam)) {                             // :70 / :97 (NaN counts as "not above")
         acc.b += 1u;
-        acc.c += -abs_tanh(lam - ratio);               // :84 / :110
+        acc.c -= abs_tanh(lam - ratio, tmode);         // :84 / :110
+    }
+}
+
+// ---- float4 forms: branch-light.  One (rarely taken) branch for the division window, one for
+// "does any of the 4 elements need the exact ratio", everything else straight-line VALU.
+__device__ __forceinline__ float fast_div(float x, float s, float r) {
+    const float q0 = x * r;
+    const float e0 = __builtin_fmaf(-s, q0, x);
+    const float q1 = __builtin_fmaf(e0, r, q0);
+    const float e1 = __builtin_fmaf(-s, q1, x);
+    return __builtin_fmaf(e1, r, q1);
+}
+
+__device__ __forceinline__ void fq_core4(const float4& x, const Ctx& c, float4& q, float4& o) {
+    // window 2^-80 <= |x| < 2^81 for all four, via min3/max3 with |.| source modifiers.  fminf/fmaxf
+    // ignore a NaN operand, which is harmless: a NaN x gives a NaN quotient on the fast path too; an
+    // all-NaN group fails the comparison and takes the IEEE path.  Inf and 0 fail the window.
+    const float amax = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+    const float amin = fminf(fminf(fabsf(x.x), fabsf(x.y)), fminf(fabsf(x.z), fabsf(x.w)));
+    float4 t;
+    if (__builtin_expect((c.fast != 0) & (amin >= 8.271806125530277e-25f) & (amax < 2.4178516392292583e+24f), 1)) {
+        t.x = fast_div(x.x, c.s, c.r);
+        t.y = fast_div(x.y, c.s, c.r);
+        t.z = fast_div(x.z, c.s, c.r);
+        t.w = fast_div(x.w, c.s, c.r);
+    } else {   // zeros, denormals, Inf, huge, or a divisor outside the window: IEEE division
+        t.x = x.x / c.s;
+        t.y = x.y / c.s;
+        t.z = x.z / c.s;
+        t.w = x.w / c.s;
+    }
+    q.x = floorf(t.x); q.y = floorf(t.y); q.z = floorf(t.z); q.w = floorf(t.w);
+    o.x = q.x * c.s; o.y = q.y * c.s; o.z = q.z * c.s; o.w = q.w * c.s;
+}
+
+__device__ __forceinline__ void vote_ctx(Ctx& c, float lam) {
+    c.lam_hi = lam * 1.000001f;
+    const float bmin = fminf(fabsf(c.s), kEpsF32);      // b = |q*s| >= |s| when q != 0, else eps (:63)
+    c.sure_ok = (lam == 0.0f || c.lam_hi * bmin >= 1.0e-30f) ? 1 : 0;
+}
+
+// exact vote of one element (IEEE ratio): custom_layers.py:64, :70/:97, :84/:110
+template <int TM>
+__device__ __forceinline__ void vote_cast(float a, float b, float lam, Acc& acc) {
+    const float ratio = a / b;
+    const bool below = !(ratio >= lam);                  // NaN counts as "not above"
+    acc.b += below ? 1u : 0u;
+    const float t = abs_tanh_t<TM>(lam - ratio);
+    acc.c -= below ? t : 0.0f;
+}
+
+template <int TM>
+__device__ __forceinline__ void vote_cast4(const float4& dy, float b0, float b1, float b2, float b3, float lam, Acc& acc) {
+    vote_cast<TM>(fabsf(dy.x), b0, lam, acc);
+    vote_cast<TM>(fabsf(dy.y), b1, lam, acc);
+    vote_cast<TM>(fabsf(dy.z), b2, lam, acc);
+    vote_cast<TM>(fabsf(dy.w), b3, lam, acc);
+}
+
+__device__ __forceinline__ void nq_accumulate4(const float4& q, const float4& o, const float4& dy, const Ctx& c, float lam,
+                                               int tmode, Acc& acc) {
+    // max|q| as a float max with |.| modifiers (q is integer-valued: exact).  A NaN q is ignored here, but
+    // then out is NaN -> ratio NaN -> the vote sum and ds are NaN anyway.
+    const float mq = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
+    acc.a = __float_as_uint(fmaxf(__uint_as_float(acc.a), mq));
+    const float b0 = (o.x == 0.0f) ? kEpsF32 : fabsf(o.x);   // :63
+    const float b1 = (o.y == 0.0f) ? kEpsF32 : fabsf(o.y);
+    const float b2 = (o.z == 0.0f) ? kEpsF32 : fabsf(o.z);
+    const float b3 = (o.w == 0.0f) ? kEpsF32 : fabsf(o.w);
+    // ratio >= lambda is certain when |dy| >= RN(lam_hi*b): a/b >= lambda(1+8e-7) > lambda and RN is monotonic.
+    // Such elements contribute nothing to the vote (:82/:108); only if some lane has an uncertain element
+    // are the four IEEE divisions done (a sure element then simply evaluates to "not below").
+    const bool all_sure = (c.sure_ok != 0) & (fabsf(dy.x) >= c.lam_hi * b0) & (fabsf(dy.y) >= c.lam_hi * b1) &
+                          (fabsf(dy.z) >= c.lam_hi * b2) & (fabsf(dy.w) >= c.lam_hi * b3);
+    if (!all_sure) {
+        if (tmode == 0) vote_cast4<0>(dy, b0, b1, b2, b3, lam, acc);        // kernel-uniform
+        else if (tmode == 1) vote_cast4<1>(dy, b0, b1, b2, b3, lam, acc);
+        else vote_cast4<2>(dy, b0, b1, b2, b3, lam, acc);
     }
 }
 
@@ -141,6 +276,8 @@ template <int OP>
 struct OpT;
 
 struct OpBase {
+    static constexpr bool kStdMerge = true;   // merge is (max, add, add): DPP reduction applies
+    static constexpr bool kVec4 = false;      // op provides elem4()
     static constexpr bool kDy = false;
     static constexpr bool kStore = false;
     static constexpr bool kReduce = false;
@@ -161,8 +298,10 @@ struct OpBase {
     __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) {
         Ctx c;
         c.s = p.s[g];
+        div_ctx(c);
         c.k0 = 0.f;
         c.k1 = 0.f;
+        vote_ctx(c, p.lam);
         return c;
     }
 };
@@ -172,8 +311,20 @@ struct OpT<OP_FWD> : OpBase {
     static constexpr bool kStore = true;
     __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float, Acc&) {
         float q, o;
-        fq_core(x, c.s, q, o);
+        fq_core(x, c, q, o);
         if (p.q) store_q(p.q, p.q_dtype, i, q);
+        return o;
+    }
+    static constexpr bool kVec4 = true;
+    __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t i, const float4& x, const float4&, Acc&) {
+        float4 q, o;
+        fq_core4(x, c, q, o);
+        if (p.q) {
+            store_q(p.q, p.q_dtype, i + 0, q.x);
+            store_q(p.q, p.q_dtype, i + 1, q.y);
+            store_q(p.q, p.q_dtype, i + 2, q.z);
+            store_q(p.q, p.q_dtype, i + 3, q.w);
+        }
         return o;
     }
 };
@@ -182,7 +333,7 @@ template <>
 struct OpT<OP_QONLY> : OpBase {
     __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float, Acc&) {
         float q, o;
-        fq_core(x, c.s, q, o);
+        fq_core(x, c, q, o);
         store_q(p.q, p.q_dtype, i, q);
         return 0.f;
     }
@@ -194,9 +345,16 @@ struct OpT<OP_BWD> : OpBase {
     static constexpr bool kReduce = true;
     __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t, float x, float dy, Acc& acc) {
         float q, o;
-        fq_core(x, c.s, q, o);
-        nq_accumulate(q, o, dy, p.lam, acc);
+        fq_core(x, c, q, o);
+        nq_accumulate(q, o, dy, p.lam, p.tmode, acc);
         return 0.f;
+    }
+    static constexpr bool kVec4 = true;
+    __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t, const float4& x, const float4& dy, Acc& acc) {
+        float4 q, o;
+        fq_core4(x, c, q, o);
+        nq_accumulate4(q, o, dy, c, p.lam, p.tmode, acc);
+        return o;
     }
 };
 
@@ -207,8 +365,15 @@ struct OpT<OP_FUSED> : OpBase {
     static constexpr bool kReduce = true;
     __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t, float x, float dy, Acc& acc) {
         float q, o;
-        fq_core(x, c.s, q, o);
-        nq_accumulate(q, o, dy, p.lam, acc);
+        fq_core(x, c, q, o);
+        nq_accumulate(q, o, dy, p.lam, p.tmode, acc);
+        return o;
+    }
+    static constexpr bool kVec4 = true;
+    __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t, const float4& x, const float4& dy, Acc& acc) {
+        float4 q, o;
+        fq_core4(x, c, q, o);
+        nq_accumulate4(q, o, dy, c, p.lam, p.tmode, acc);
         return o;
     }
 };
@@ -217,6 +382,7 @@ struct OpT<OP_FUSED> : OpBase {
 template <>
 struct OpT<OP_MAXBIN_FWD> : OpBase {
     static constexpr bool kReduce = true;
+    static constexpr bool kStdMerge = false;
     template <typename A, typename B>
     __device__ static __forceinline__ void merge(A& x, const B& y) {
         if (y.a > x.a) {
@@ -246,6 +412,10 @@ struct OpT<OP_MAXBIN_BWD> : OpBase {
     __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) {
         Ctx c;
         c.s = p.s[g];
+        c.r = 0.f;
+        c.fast = 0;
+        c.lam_hi = 0.f;
+        c.sure_ok = 0;
         c.k0 = p.mb[g];
         float up = p.c_dev[0] * p.c_scale;
         c.k1 = (up / (float)p.G) / (float)p.ties[g];
@@ -277,6 +447,10 @@ struct OpT<OP_DIFF_BWD> : OpBase {
     __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) {
         Ctx c;
         c.s = p.s[g];
+        c.r = 0.f;
+        c.fast = 0;
+        c.lam_hi = 0.f;
+        c.sure_ok = 0;
         double n = (double)p.outer * (double)p.G * (double)p.inner;
         c.k0 = (p.c_dev[0] * p.c_scale) / (float)n;
         c.k1 = 0.f;
@@ -329,16 +503,105 @@ __device__ __forceinline__ void write_partial(const Params& p, int64_t idx, cons
 }
 
 // ------------------------------------------------------------------------------------------
-//  Traversal 1 -- "row big": rows of length L >= 1024; one block per (row, chunk) unit.
-//  The scale is block-uniform.  VEC = 4: float4 loads/stores (L % 4 == 0, 16-B aligned bases).
+//  DPP wave reduction for the standard accumulator (a: max, b: add, c: add) -- VALU only, no LDS
+//  crossbar traffic: quad_perm x2, row_half_mirror, row_mirror give every lane of a 16-lane row
+//  the row total; row_bcast15 / row_bcast31 carry it across rows; lane 63 ends with the total.
+//  The combination order is fixed, so float sums are run-to-run bit-stable.
 // ------------------------------------------------------------------------------------------
-template <int OP, int VEC>
-__global__ __launch_bounds__(kBlock) void k_row_big(Params p, int64_t L, int CH, int64_t nc) {
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_step(Acc& acc) {
+    const uint32_t a = dpp_u32<CTRL, ROW_MASK>(0u, acc.a);
+    const uint32_t b = dpp_u32<CTRL, ROW_MASK>(0u, acc.b);
+    const float c = __uint_as_float(dpp_u32<CTRL, ROW_MASK>(0u, __float_as_uint(acc.c)));
+    acc.a = a > acc.a ? a : acc.a;
+    acc.b += b;
+    acc.c += c;
+}
+__device__ __forceinline__ void dpp_row_reduce(Acc& acc) {   // every lane of each 16-lane row <- row total
+    dpp_step<0xB1, 0xf>(acc);    // quad_perm [1,0,3,2]
+    dpp_step<0x4E, 0xf>(acc);    // quad_perm [2,3,0,1]
+    dpp_step<0x141, 0xf>(acc);   // row_half_mirror
+    dpp_step<0x140, 0xf>(acc);   // row_mirror
+}
+__device__ __forceinline__ void dpp_wave_reduce(Acc& acc) {  // lane 63 <- wave total
+    dpp_row_reduce(acc);
+    dpp_step<0x142, 0xa>(acc);   // row_bcast15 into rows 1 and 3
+    dpp_step<0x143, 0xc>(acc);   // row_bcast31 into rows 2 and 3
+}
+
+// Block reduction for the standard accumulator; result valid in thread 0.  BS multiple of 64, <= 1024.
+template <int BS>
+__device__ __forceinline__ void block_reduce_dpp(Acc& acc) {
+    constexpr int NW = BS / 64;
+    __shared__ uint32_t sa[NW], sb[NW];
+    __shared__ float sc[NW];
+    dpp_wave_reduce(acc);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 63) {
+        sa[wid] = acc.a;
+        sb[wid] = acc.b;
+        sc[wid] = acc.c;
+    }
+    __syncthreads();
+    if (wid == 0) {
+        Acc r;
+        r.a = lane < NW ? sa[lane] : 0u;
+        r.b = lane < NW ? sb[lane] : 0u;
+        r.c = lane < NW ? sc[lane] : 0.f;
+        dpp_row_reduce(r);       // NW <= 16: one row holds every wave's partial
+        acc = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Traversal 1 -- "row stream": rows of length L >= 1024.  One block per (row, chunk) unit of
+//  BS*4 elements; every thread owns exactly ONE float4 of each stream (measured on MI355X,
+//  tools/membench.hip: this shape with nontemporal accesses streams 2 reads at 6.8 TB/s, read+write
+//  at 6.5 TB/s, 2 reads + write at 6.5 TB/s; multi-float4-per-thread loops and persistent blocks
+//  are 5-15 % slower).  The scale is block-uniform.  Grid is 3-D (chunk, g, outer) so that no integer
+//  division is needed; a 1-D grid with division is the fallback for huge G / outer.
+//  VEC = 4: float4 accesses (L % 4 == 0 or a single flat row; 16-B aligned bases).
+//  NT: nontemporal loads/stores (streamed-once tensors far larger than the caches).
+// ------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__device__ __forceinline__ float4 load4(const float* p) {
+    if (NT) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+template <int NT>
+__device__ __forceinline__ void store4(float* p, const float4& v) {
+    if (NT) {
+        const v4f t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+    } else {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
+
+template <int OP, int VEC, int BS, int NT>
+__global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params p, int64_t L, int64_t nc, int grid3d) {
     using O = OpT<OP>;
-    const int64_t unit = blockIdx.x;
-    const int64_t row = unit / nc;
-    const int64_t ck = unit - row * nc;
-    const int64_t g = row % p.G;
+    constexpr int CH = BS * 4;
+    int64_t row, ck, g;
+    if (grid3d) {
+        ck = blockIdx.x;
+        g = blockIdx.y;
+        row = (int64_t)blockIdx.z * p.G + g;
+    } else {
+        const int64_t unit = blockIdx.x;
+        row = unit / nc;
+        ck = unit - row * nc;
+        g = row % p.G;
+    }
     const Ctx ctx = O::ctx(p, g);
     const int64_t base = row * L + ck * (int64_t)CH;
     const int64_t rem = L - ck * (int64_t)CH;
@@ -346,35 +609,25 @@ __global__ __launch_bounds__(kBlock) void k_row_big(Params p, int64_t L, int CH,
     Acc acc = O::template init<Acc>();
 
     if (VEC == 4) {
-        const float4* P4 = reinterpret_cast<const float4*>(p.P + base);
-        const float4* D4 = reinterpret_cast<const float4*>(O::kDy ? p.dy + base : p.P + base);
-        float4* O4 = reinterpret_cast<float4*>(O::kStore ? p.out + base : nullptr);
         const int len4 = len >> 2;
-        for (int it = 0; it < len4; it += kBlock * kUnroll) {
-            float4 x[kUnroll], d[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const int j = it + u * kBlock + (int)threadIdx.x;
-                if (j < len4) {
-                    x[u] = P4[j];
-                    if (O::kDy) d[u] = D4[j];
-                }
+        const int j = (int)threadIdx.x;
+        if (j < len4) {
+            const int64_t i = base + (int64_t)j * 4;
+            const float4 x = load4<NT>(p.P + i);
+            float4 d = x;
+            if (O::kDy) d = load4<NT>(p.dy + i);
+            float4 r;
+            if constexpr (O::kVec4) {
+                r = O::elem4(p, ctx, i, x, d, acc);
+            } else {
+                r.x = O::elem(p, ctx, i + 0, x.x, O::kDy ? d.x : 0.f, acc);
+                r.y = O::elem(p, ctx, i + 1, x.y, O::kDy ? d.y : 0.f, acc);
+                r.z = O::elem(p, ctx, i + 2, x.z, O::kDy ? d.z : 0.f, acc);
+                r.w = O::elem(p, ctx, i + 3, x.w, O::kDy ? d.w : 0.f, acc);
             }
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const int j = it + u * kBlock + (int)threadIdx.x;
-                if (j < len4) {
-                    const int64_t i = base + (int64_t)j * 4;
-                    float4 r;
-                    r.x = O::elem(p, ctx, i + 0, x[u].x, O::kDy ? d[u].x : 0.f, acc);
-                    r.y = O::elem(p, ctx, i + 1, x[u].y, O::kDy ? d[u].y : 0.f, acc);
-                    r.z = O::elem(p, ctx, i + 2, x[u].z, O::kDy ? d[u].z : 0.f, acc);
-                    r.w = O::elem(p, ctx, i + 3, x[u].w, O::kDy ? d[u].w : 0.f, acc);
-                    if (O::kStore) O4[j] = r;
-                }
-            }
+            if (O::kStore) store4<NT>(p.out + i, r);
         }
-        // ragged tail (only a single flat row, G == 1, can have len % 4 != 0 on the vector path)
+        // ragged scalar tail: only a single flat row (G == 1) can have len % 4 != 0 on the vector path
         const int tail = len & 3;
         if ((int)threadIdx.x < tail) {
             const int64_t i = base + (int64_t)len4 * 4 + threadIdx.x;
@@ -382,29 +635,30 @@ __global__ __launch_bounds__(kBlock) void k_row_big(Params p, int64_t L, int CH,
             if (O::kStore) p.out[i] = r;
         }
     } else {
-        for (int it = 0; it < len; it += kBlock * kUnroll) {
-            float x[kUnroll], d[kUnroll];
+        float x[4], d[4];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const int j = it + u * kBlock + (int)threadIdx.x;
-                if (j < len) {
-                    x[u] = p.P[base + j];
-                    if (O::kDy) d[u] = p.dy[base + j];
-                }
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int j = u * BS + (int)threadIdx.x;
+            const int jc = j < len ? j : len - 1;      // clamp instead of predicate: the loads stay in flight together
+            x[u] = p.P[base + jc];
+            d[u] = O::kDy ? p.dy[base + jc] : 0.f;
+        }
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const int j = it + u * kBlock + (int)threadIdx.x;
-                if (j < len) {
-                    float r = O::elem(p, ctx, base + j, x[u], O::kDy ? d[u] : 0.f, acc);
-                    if (O::kStore) p.out[base + j] = r;
-                }
+        for (int u = 0; u < 4; ++u) {
+            const int j = u * BS + (int)threadIdx.x;
+            if (j < len) {
+                float r = O::elem(p, ctx, base + j, x[u], d[u], acc);
+                if (O::kStore) p.out[base + j] = r;
             }
         }
     }
     if (O::kReduce) {
-        block_reduce<O, Acc, kBlock>(acc);
-        if (threadIdx.x == 0) write_partial(p, unit, acc);
+        if constexpr (O::kStdMerge) {
+            block_reduce_dpp<BS>(acc);
+        } else {
+            block_reduce<O, Acc, BS>(acc);
+        }
+        if (threadIdx.x == 0) write_partial(p, row * nc + ck, acc);
     }
 }
 
@@ -601,21 +855,22 @@ __global__ void k_inverse_bwd(const float* s, const float* c_dev, float c_scale,
     ds[g] = (sg == 0.0f) ? 0.0f : -((up / (float)G) / sg) / sg;
 }
 
-__global__ void k_adam(float* s, const float* ds, float* m, float* v, int64_t n, float lr, float b1, float b2,
-                       float eps, float b1p, float b2p, float min_value, int mode) {
+// f0..f3 are host-computed factors (python-double arithmetic rounded to fp32, as Keras / torch do):
+//   keras: f0 = 1-b1, f1 = 1-b2, f2 = alpha = lr*sqrt(1-b2^t)/(1-b1^t), f3 = eps
+//   torch: f0 = 1-b1, f1 = 1-b2, f2 = lr/(1-b1^t), f3 = eps, f4 = sqrt(1-b2^t)
+__global__ void k_adam(float* s, const float* ds, float* m, float* v, int64_t n, float f0, float f1, float f2, float f3,
+                       float f4, float min_value, int mode) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float g = ds[i];
     float mi = m[i], vi = v[i], w = s[i];
-    mi = mi + (g - mi) * (1.0f - b1);
-    vi = vi + (g * g - vi) * (1.0f - b2);
+    mi = mi + (g - mi) * f0;
+    vi = vi + (g * g - vi) * f1;
     if (mode == LQ_ADAM_KERAS) {
-        const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
-        w = w - (mi * alpha) / (sqrtf(vi) + eps);
+        w = w - (mi * f2) / (sqrtf(vi) + f3);
     } else {
-        const float mh = mi / (1.0f - b1p);
-        const float denom = sqrtf(vi) / sqrtf(1.0f - b2p) + eps;
-        w = w - lr * (mh / denom);
+        const float denom = sqrtf(vi) / f4 + f3;
+        w = w - f2 * (mi / denom);
     }
     w = (w < min_value) ? min_value : w;   // MinValueConstraint: max(w, min_value); NaN stays NaN
     m[i] = mi;
@@ -639,9 +894,15 @@ __global__ void k_q_absmax_axis(const float* P, const float* s, float* result, i
     uint32_t best = 0u;
     for (int64_t k = 0; k < n_axis; ++k) {
         const int64_t i = (a * n_axis + k) * post + b;
-        const float sg = s[(i / inner) % G];
+        Ctx c;
+        c.s = s[(i / inner) % G];
+        c.r = 0.f;
+        c.fast = 0;
+        c.lam_hi = 0.f;
+        c.sure_ok = 0;
+        c.k0 = c.k1 = 0.f;
         float q, o;
-        fq_core(P[i], sg, q, o);
+        fq_core(P[i], c, q, o);
         const uint32_t bits = __float_as_uint(fabsf(q));
         best = bits > best ? bits : best;
     }
@@ -656,6 +917,7 @@ enum Mode { MODE_ROW_BIG = 0, MODE_ROW_SMALL = 1, MODE_COL = 2 };
 struct Plan {
     int mode;
     int64_t R, L;       // row modes
+    int bs;             // threads per block in the streaming traversal (unit = bs*4 elements)
     int CH;
     int64_t nc;
     int lpr_log2;
@@ -712,10 +974,9 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner) {
         pl.L = L;
         if (L >= 1024) {
             pl.mode = MODE_ROW_BIG;
-            const int64_t nc0 = ceil_div(L, kChunkMax);
-            int64_t ch = ceil_div(ceil_div(L, nc0), 1024) * 1024;
-            pl.CH = (int)ch;
-            pl.nc = ceil_div(L, ch);
+            pl.bs = L >= 4096 ? 1024 : (L >= 2048 ? 512 : 256);
+            pl.CH = pl.bs * 4;
+            pl.nc = ceil_div(L, pl.CH);
         } else {
             pl.mode = MODE_ROW_SMALL;
             pl.CH = (int)L;
@@ -785,11 +1046,29 @@ static int launch_traverse(const Plan& pl, const Params& p, hipStream_t st) {
     if (pl.mode == MODE_ROW_BIG) {
         const int64_t units = pl.R * pl.nc;
         if (units > 2147483647ll) return fail(LQ_EINVAL, "too many work units (%lld)", (long long)units);
-        bool vec = (pl.L % 4 == 0 || pl.R == 1) && aligned(p.P, 16) && (!O::kDy || aligned(p.dy, 16)) && (!O::kStore || aligned(p.out, 16));
-        if (vec)
-            hipLaunchKernelGGL((k_row_big<OP, 4>), dim3((unsigned)units), dim3(kBlock), 0, st, p, pl.L, pl.CH, pl.nc);
-        else
-            hipLaunchKernelGGL((k_row_big<OP, 1>), dim3((unsigned)units), dim3(kBlock), 0, st, p, pl.L, pl.CH, pl.nc);
+        const bool vec = (pl.L % 4 == 0 || pl.R == 1) && aligned(p.P, 16) && (!O::kDy || aligned(p.dy, 16)) &&
+                         (!O::kStore || aligned(p.out, 16));
+        const int64_t outer_f = pl.R / p.G;
+        const int grid3d = (p.G <= 65535 && outer_f <= 65535 && pl.R == outer_f * p.G) ? 1 : 0;
+        const dim3 grid = grid3d ? dim3((unsigned)pl.nc, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)units);
+        const bool nt = vec && pl.bs == 1024 && (double)pl.R * (double)pl.L * 4.0 >= (double)kNtBytes;
+#define LQ_LAUNCH_STREAM(VEC_, BS_, NT_) \
+        hipLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_>), grid, dim3(BS_), 0, st, p, pl.L, pl.nc, grid3d)
+        if (vec) {
+            if (pl.bs == 1024) {
+                if (nt) LQ_LAUNCH_STREAM(4, 1024, 1);
+                else LQ_LAUNCH_STREAM(4, 1024, 0);
+            } else if (pl.bs == 512) {
+                LQ_LAUNCH_STREAM(4, 512, 0);
+            } else {
+                LQ_LAUNCH_STREAM(4, 256, 0);
+            }
+        } else {
+            if (pl.bs == 1024) LQ_LAUNCH_STREAM(1, 1024, 0);
+            else if (pl.bs == 512) LQ_LAUNCH_STREAM(1, 512, 0);
+            else LQ_LAUNCH_STREAM(1, 256, 0);
+        }
+#undef LQ_LAUNCH_STREAM
     } else if (pl.mode == MODE_ROW_SMALL) {
         const int rpb = kBlock >> pl.lpr_log2;
         const int64_t blocks = ceil_div(pl.R, rpb);
@@ -808,9 +1087,9 @@ static int launch_finalize(const Params& p, FinGeom f, hipStream_t st) {
     const int64_t n = f.n1 * f.n2;
     if (n <= 32) {
         hipLaunchKernelGGL((k_finalize_thread<OP>), dim3((unsigned)ceil_div(f.groups, kBlock)), dim3(kBlock), 0, st, p, f);
-    } else if (n <= 512) {
+    } else if (n <= 256) {
         hipLaunchKernelGGL((k_finalize_block<OP, 64>), dim3((unsigned)f.groups), dim3(64), 0, st, p, f);
-    } else if (n <= 4096) {
+    } else if (n <= 1024) {
         hipLaunchKernelGGL((k_finalize_block<OP, 256>), dim3((unsigned)f.groups), dim3(256), 0, st, p, f);
     } else {
         hipLaunchKernelGGL((k_finalize_block<OP, 1024>), dim3((unsigned)f.groups), dim3(1024), 0, st, p, f);
@@ -918,6 +1197,7 @@ int lq_fq_scale_grad(const float* P, const float* s, const float* dy, float lamb
     Params p = base_params(P, s, outer, G, inner);
     p.dy = dy;
     p.lam = lambda;
+    p.tmode = (lambda < 4.0e-4f) ? 0 : ((lambda <= 0.25f) ? 1 : 2);   // NaN lambda -> 2
     if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
     if ((rc = launch_traverse<OP_BWD>(pl, p, (hipStream_t)stream))) return rc;
     FinGeom f = group_geom(pl, outer, G, inner);
@@ -939,6 +1219,7 @@ int lq_fq_fwd_bwd_fused(const float* P, const float* s, const float* dy, float l
     Params p = base_params(P, s, outer, G, inner);
     p.dy = dy;
     p.lam = lambda;
+    p.tmode = (lambda < 4.0e-4f) ? 0 : ((lambda <= 0.25f) ? 1 : 2);   // NaN lambda -> 2
     p.out = out;
     if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
     if ((rc = launch_traverse<OP_FUSED>(pl, p, (hipStream_t)stream))) return rc;
@@ -1045,8 +1326,8 @@ int lq_penalty_inverse_bwd(const float* s, const float* c_dev, float c_scale, fl
     return check_hip("inverse bwd launch");
 }
 
-int lq_scale_adam_step(float* s, const float* ds, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                       float eps, int64_t step, float min_value, int mode, void* stream) {
+int lq_scale_adam_step(float* s, const float* ds, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                       double eps, int64_t step, float min_value, int mode, void* stream) {
     if (n <= 0) return fail(LQ_EINVAL, "lq_scale_adam_step: n must be positive");
     if (step < 1) return fail(LQ_EINVAL, "lq_scale_adam_step: step is 1-based");
     if (mode != LQ_ADAM_KERAS && mode != LQ_ADAM_TORCH) return fail(LQ_EINVAL, "lq_scale_adam_step: bad mode %d", mode);
@@ -1054,8 +1335,19 @@ int lq_scale_adam_step(float* s, const float* ds, float* m, float* v, int64_t n,
     LQ_REQUIRE_PTR(ds);
     LQ_REQUIRE_PTR(m);
     LQ_REQUIRE_PTR(v);
-    const float b1p = powf(beta1, (float)step), b2p = powf(beta2, (float)step);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, s, ds, m, v, n, lr, beta1, beta2, eps, b1p, b2p, min_value, mode);
+    const float f0 = (float)(1.0 - beta1), f1 = (float)(1.0 - beta2);
+    float f2, f4 = 1.0f;
+    if (mode == LQ_ADAM_KERAS) {
+        // Keras 2.11: beta powers in fp32 (tf.pow on the cast hyper-parameter), alpha in fp32
+        const float b1p = powf((float)beta1, (float)step), b2p = powf((float)beta2, (float)step);
+        f2 = (float)lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    } else {
+        // torch.optim.Adam: bias corrections in python doubles
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        f2 = (float)(lr / bc1);
+        f4 = (float)sqrt(bc2);
+    }
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, s, ds, m, v, n, f0, f1, f2, (float)eps, f4, min_value, mode);
     return check_hip("adam launch");
 }
 

@@ -157,7 +157,7 @@ def test_scale_adam_matches_keras_restatement(dev):
     opt = lq.ScaleAdam([p], lr=1e-4)
     s, m, v = s0.copy(), np.zeros(64, np.float32), np.zeros(64, np.float32)
     for step in range(1, 6):
-        g = rng.normal(0, 1.0, size=64).astype(np.float32) * (10.0 ** rng.integers(-6, 1))
+        g = (rng.normal(0, 1.0, size=64) * (10.0 ** rng.integers(-6, 1))).astype(np.float32)
         p.grad = torch.tensor(g, device=dev)
         opt.step()
         s, m, v = O.keras_adam_step(s, g, m, v, step, lr=1e-4, min_value=O.SCALE_MIN)
