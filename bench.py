@@ -5,7 +5,10 @@
 
 Workload: synthetic conv-activation batch
 256 x 3 x 224 x 224 fp32 per GPU (x ~ U[0,255), dy ~ N(0,1e-3), seed 42), per-channel scales
-s = [0.5, 1, 2] (outer=256, G=3, inner=50176), threshold lambda = 1e-3.
+s = [0.5, 1, 2] (outer=256, G=3, inner=50176), threshold lambda = 1e-11 -- the best threshold the
+reference publishes for CIFAR-10 (thesis chapter4.tex:225-226), the dataset BASELINE.json's metric names.
+("extras" in the JSON line also reports lambda = 1e-3, where every element takes the exact-ratio +
+tanh branch, the single-pass fused kernel K4, and the per-tensor scale variant.)
 One STEP = what one training iteration does to that tensor on the hot path, through the C ABI:
     forward   lq_fq_forward      out = floor(x/s)*s                    (K1, 8 B/element)
     backward  lq_fq_scale_grad   ds = mean_g(vote) * max_g|q|          (K2+K3, 8 B/element; dP aliases dy)
@@ -16,7 +19,10 @@ processes its own 256-image shard (weak scaling) and the learned-scale gradient 
 each step -- the only exchange this path has.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  "roofline":     dominant kernel vs the 8 TB/s HBM peak, duration from HIP events inside the timed region
+  "roofline":     dominant kernel vs the 8 TB/s HBM peak, duration from HIP events recorded inside the timed
+                  region on the launch stream (every 10th step: an event pair costs ~3 us of stream time, and
+                  recording around every launch would slow the loop it measures by ~9 %); "traffic" = HBM bytes
+                  per launch from the committed rocprofv3 PMC passes (profiles/traffic.json)
   "cpu_baseline": the op-for-op torch-CPU restatement of the reference path (oracle/lq_oracle_torch.py)
                   timed on this box's host cores on a bounded sample -- a baseline, not a target.
 """
@@ -48,13 +54,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--lam", type=float, default=1e-3)
+    ap.add_argument("--lam", type=float, default=1e-11)
     ap.add_argument("--variant", choices=["split", "fused"], default="split",
                     help="split = K1 then K2+K3 (what autograd runs); fused = K4 single pass")
     ap.add_argument("--scale", choices=["per_channel", "per_tensor"], default="per_channel")
     ap.add_argument("--sets", type=int, default=4, help="rotating buffer sets (>= 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-every", type=int, default=10, help="record per-kernel HIP events every Nth timed step (0 = never)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (one graph per buffer set)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational extra measurements (N=1 only)")
     return ap.parse_args()
 
 
@@ -159,9 +168,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    graphs = None
+    if args.graph:
+        # one captured graph per buffer set: the launch-bound inner loop becomes one hipGraphLaunch per step
+        graphs = []
+        side = torch.cuda.Stream(dev)
+        with torch.cuda.stream(side):
+            for k in range(nsets):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph, stream=side):
+                    cs = torch.cuda.current_stream(dev).cuda_stream or None
+                    if args.variant == "split":
+                        rc = fwd(px[k], ps, pout[k], None, 0, outer, G, inner, cs)
+                        rc |= bwd(px[k], ps, pdy[k], lam, pds, None, pws, ws_bytes, outer, G, inner, cs)
+                    else:
+                        rc = fused(px[k], ps, pdy[k], lam, pout[k], pds, pws, ws_bytes, outer, G, inner, cs)
+                    if rc:
+                        _hip.check(rc, "graph capture")
+                graphs.append(gph)
+        torch.cuda.synchronize(dev)
+
+        def step(i, ev=None):  # noqa: F811
+            if ev:
+                ev[0].record(stream)
+            graphs[i % nsets].replay()
+            if ev:
+                ev[2].record(stream)
+            if world > 1:
+                dist.all_reduce(ds, op=dist.ReduceOp.SUM)
+
     for i in range(args.warmup):
         step(i)
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    ee = args.event_every
+    events = [([torch.cuda.Event(enable_timing=True) for _ in range(3)] if (ee and i % ee == 0) else None)
+              for i in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -172,23 +212,76 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    events = [e for e in events if e is not None]
+    nev = max(len(events), 1)
 
     # per-kernel durations from the HIP events recorded inside the timed region
-    if args.variant == "split":
-        t_fwd = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps * 1e-3
-        t_bwd = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps * 1e-3
+    if not events:
+        t_fwd = t_bwd = kt = float("nan")
+        kname, kbytes, step_bytes, extra = "n/a", 0, (BYTES_FUSED if args.variant == "fused" else BYTES_FWD + BYTES_BWD), {}
+    elif args.variant == "split" and not args.graph:
+        t_fwd = sum(e[0].elapsed_time(e[1]) for e in events) / nev * 1e-3
+        t_bwd = sum(e[1].elapsed_time(e[2]) for e in events) / nev * 1e-3
         if t_bwd >= t_fwd:
-            kname, kbytes, kt = "k_row_big<OP_BWD> (+finalize)", BYTES_BWD, t_bwd
+            kname, kbytes, kt = "k_row_stream<OP_BWD> (+finalize)", BYTES_BWD, t_bwd
         else:
-            kname, kbytes, kt = "k_row_big<OP_FWD>", BYTES_FWD, t_fwd
+            kname, kbytes, kt = "k_row_stream<OP_FWD>", BYTES_FWD, t_fwd
         step_bytes = BYTES_FWD + BYTES_BWD
         extra = {"t_fwd_us": t_fwd * 1e6, "t_bwd_us": t_bwd * 1e6,
                  "fwd_GBs": BYTES_FWD / t_fwd / 1e9, "bwd_GBs": BYTES_BWD / t_bwd / 1e9}
     else:
-        kt = sum(e[0].elapsed_time(e[2]) for e in events) / args.steps * 1e-3
-        kname, kbytes = "k_row_big<OP_FUSED> (+finalize)", BYTES_FUSED
-        step_bytes = BYTES_FUSED
-        extra = {"t_fused_us": kt * 1e6}
+        kt = sum(e[0].elapsed_time(e[2]) for e in events) / nev * 1e-3
+        if args.variant == "fused":
+            kname, kbytes = "k_row_stream<OP_FUSED> (+finalize)", BYTES_FUSED
+        else:
+            kname, kbytes = "graph(k_row_stream<OP_FWD>, k_row_stream<OP_BWD>, finalize)", BYTES_FWD + BYTES_BWD
+        step_bytes = kbytes
+        extra = {"t_step_kernels_us": kt * 1e6}
+
+    # ---- informational extras (not part of `value`): other variants of the same step, 100 steps each, no events
+    extras = {}
+    if world == 1 and not args.no_extras and not args.graph:
+        def timed(fn, n=100):
+            for i in range(10):
+                fn(i)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / n
+
+        def split_step(lm, sc):
+            sp_, o_, g_, in_ = sc
+            def f(i):
+                k = i % nsets
+                fwd(px[k], sp_, pout[k], None, 0, o_, g_, in_, sp)
+                bwd(px[k], sp_, pdy[k], lm, pds, None, pws, ws_bytes, o_, g_, in_, sp)
+            return f
+
+        def fused_step(lm, sc):
+            sp_, o_, g_, in_ = sc
+            def f(i):
+                k = i % nsets
+                fused(px[k], sp_, pdy[k], lm, pout[k], pds, pws, ws_bytes, o_, g_, in_, sp)
+            return f
+
+        s1 = torch.tensor([1.0], device=dev)
+        ws1 = lib.lq_workspace_bytes(1, 1, ELEMS)
+        assert ws1 <= ws_bytes or args.scale == "per_tensor"
+        pc = (ps, outer, G, inner)
+        pt = (s1.data_ptr(), 1, 1, ELEMS)
+        for name, fn, nbytes in (
+                ("split_lambda_1e-3", split_step(1e-3, pc), BYTES_FWD + BYTES_BWD),
+                ("split_lambda_0", split_step(0.0, pc), BYTES_FWD + BYTES_BWD),
+                (f"fused_K4_lambda_{lam:g}", fused_step(lam, pc), BYTES_FUSED),
+                ("fused_K4_lambda_1e-3", fused_step(1e-3, pc), BYTES_FUSED),
+                (f"split_per_tensor_scale_lambda_{lam:g}", split_step(lam, pt), BYTES_FWD + BYTES_BWD)):
+            if "per_tensor" in name and ws1 > ws_bytes:
+                continue
+            dt = timed(fn)
+            extras[name] = {"images_per_s": BATCH / dt, "us_per_step": dt * 1e6, "step_GBs": nbytes / dt / 1e9,
+                            "algorithmic_bytes_per_step": nbytes}
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -225,6 +318,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": kbytes, "avg_launch_us": kt * 1e6, **extra},
         }
+        if world == 1 and not args.no_extras and not args.graph:
+            line["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(lam, args.cpu_seconds)
         else:

@@ -602,7 +602,6 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params 
         ck = unit - row * nc;
         g = row % p.G;
     }
-    const Ctx ctx = O::ctx(p, g);
     const int64_t base = row * L + ck * (int64_t)CH;
     const int64_t rem = L - ck * (int64_t)CH;
     const int len = rem < (int64_t)CH ? (int)rem : CH;
@@ -611,11 +610,19 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params 
     if (VEC == 4) {
         const int len4 = len >> 2;
         const int j = (int)threadIdx.x;
+        // Issue the streaming loads FIRST (they depend only on the kernel arguments and the block index);
+        // the per-group context (scale fetch, reciprocal, thresholds) is computed while they are in flight.
+        // Inactive lanes of a partial chunk re-read float4 0 of the chunk instead of branching.
+        // A chunk with fewer than 4 elements (len4 == 0; only the last chunk of a flat row, so ck > 0)
+        // reads the float4 just before it: always in bounds, never used.
+        const int64_t i = base + (int64_t)(j < len4 ? j : 0) * 4;
+        const int64_t il = len4 > 0 ? i : base - 4;
+        const float4 x = load4<NT>(p.P + il);
+        float4 d = x;
+        if (O::kDy) d = load4<NT>(p.dy + il);
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the scale fetch + reciprocal below
+        const Ctx ctx = O::ctx(p, g);
         if (j < len4) {
-            const int64_t i = base + (int64_t)j * 4;
-            const float4 x = load4<NT>(p.P + i);
-            float4 d = x;
-            if (O::kDy) d = load4<NT>(p.dy + i);
             float4 r;
             if constexpr (O::kVec4) {
                 r = O::elem4(p, ctx, i, x, d, acc);
@@ -643,6 +650,7 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params 
             x[u] = p.P[base + jc];
             d[u] = O::kDy ? p.dy[base + jc] : 0.f;
         }
+        const Ctx ctx = O::ctx(p, g);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = u * BS + (int)threadIdx.x;
