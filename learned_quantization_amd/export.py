@@ -1,0 +1,77 @@
+"""Integer export + compression (SURVEY f-1): the reference's end-of-run artefact.
+
+Mirrors ``save_compress_parameters`` of
+/root/reference/CIFAR-10/nested_quantization_layer/utils/log_scripts.py:61-97:
+
+    weights[layer.name + '/W'] = floor(kernel / scale).astype(int8)      (:74-76)
+    weights[layer.name + '/b'] = floor(b / b_scale).astype(int8)         (:77-79)
+    np.save(log_dir/weights.npy, weights)  -> zip(ZIP_DEFLATED) -> file_sizes.log in MB  (:83-97)
+
+The integers come from the HIP kernel K1 (``q_dtype = int8``: the same two's-complement wrap as
+``astype(np.int8)``; the reference's cast silently wraps when |q| > 127, e.g. at the initial scale).
+Layouts are the reference's (HWIO / (in,out)), so the arrays are byte-compatible.  Plain (non-custom)
+conv/dense layers are stored in float32 like the reference does for "conv2d" layers (:80-82).
+The reference does not store the scales (thesis chapter4.tex:328-330 notes they must be kept separately);
+``scales.npz`` is written next to the archive as an extension.
+"""
+from __future__ import annotations
+
+import os
+import zipfile
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import ops
+from .layers import CustomDenseLayer, _ConvBase
+
+
+def quantized_state(model: torch.nn.Module) -> Dict[str, np.ndarray]:
+    weights: Dict[str, np.ndarray] = {}
+    for layer in model.modules():
+        if isinstance(layer, _ConvBase):
+            weights[layer.name + "/W"] = ops.quantized_integers(layer.kernel.data, layer.nested_q_k_layer.scale.data,
+                                                                torch.int8).cpu().numpy()
+            if layer._has_bias:
+                weights[layer.name + "/b"] = ops.quantized_integers(layer.b.data, layer.nested_q_b_layer.scale.data,
+                                                                    torch.int8).cpu().numpy()
+        elif isinstance(layer, CustomDenseLayer):
+            weights[layer.name + "/W"] = ops.quantized_integers(layer.W.data, layer.nested_q_w_layer.scale.data,
+                                                                torch.int8).cpu().numpy()
+            weights[layer.name + "/b"] = ops.quantized_integers(layer.b.data, layer.nested_q_b_layer.scale.data,
+                                                                torch.int8).cpu().numpy()
+    return weights
+
+
+def scale_state(model: torch.nn.Module) -> Dict[str, np.ndarray]:
+    out = {}
+    for layer in model.modules():
+        for attr, tag in (("nested_q_k_layer", "/W_scale"), ("nested_q_w_layer", "/W_scale"), ("nested_q_b_layer", "/b_scale")):
+            nested = getattr(layer, attr, None)
+            if nested is not None and getattr(nested, "scale", None) is not None and hasattr(layer, "name"):
+                out[layer.name + tag] = nested.scale.detach().cpu().numpy()
+    return out
+
+
+def save_compress_parameters(model: torch.nn.Module, log_dir: str) -> Dict[str, float]:
+    """Writes weights.npy, weights.zip, file_sizes.log (reference format) and scales.npz; returns sizes in MB."""
+    os.makedirs(log_dir, exist_ok=True)
+    weights_path = os.path.join(log_dir, "weights.npy")
+    weights = quantized_state(model)
+    for name, layer in model.named_modules():
+        if isinstance(layer, (torch.nn.Conv2d, torch.nn.Linear)):            # log_scripts.py:80-82
+            weights[name + "/W"] = layer.weight.detach().cpu().numpy()
+            if layer.bias is not None:
+                weights[name + "/b"] = layer.bias.detach().cpu().numpy()
+    np.save(weights_path, weights)                                             # pickled dict, like the reference
+    zip_file_path = os.path.join(log_dir, "weights.zip")
+    with zipfile.ZipFile(zip_file_path, "w", compression=zipfile.ZIP_DEFLATED) as zipf:
+        zipf.write(weights_path, arcname="weights.npy")
+    np.savez(os.path.join(log_dir, "scales.npz"), **scale_state(model))
+    size = os.path.getsize(weights_path) / (1024 * 1024)
+    zip_size = os.path.getsize(zip_file_path) / (1024 * 1024)
+    with open(os.path.join(log_dir, "file_sizes.log"), "w") as log_file:
+        log_file.write(f"Weights size: {size:.4f} MB\n")
+        log_file.write(f"Compressed weights size: {zip_size:.4f} MB\n")
+    return {"weights_mb": size, "zip_mb": zip_size}

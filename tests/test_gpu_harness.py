@@ -1,0 +1,111 @@
+"""GPU tests of the "next" rows: end-to-end training step (f-3), integer export (f-1), tracking statistics (f-2)."""
+import os
+import zipfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("config,mode,loss,orient", [
+    ("mnist", "nq", None, "rowwise"), ("mnist", "cl", "difference", "columnwise"),
+    ("cifar", "nq", None, "channelwise"), ("cifar", "cl", "maxbin", "rowwise"), ("cifar", "cl", "inverse", "scalar"),
+])
+def test_training_steps_run_and_respect_invariants(dev, config, mode, loss, orient, tmp_path):
+    from learned_quantization_amd.train import Trainer, synthetic_batch
+    value = 1e-3 if mode == "nq" else 1e-2
+    tr = Trainer(config, mode, value, orient, loss, device=dev, log_dir=str(tmp_path))
+    x, y = synthetic_batch(config, 16, dev, torch.Generator(device=dev).manual_seed(0))
+    scales0 = [s.detach().clone() for s in tr.scale_opt.param_groups[0]["params"]]
+    losses = [float(tr.step(x, y)) for _ in range(3)]
+    assert all(np.isfinite(l) for l in losses)
+    scales = tr.scale_opt.param_groups[0]["params"]
+    assert all(float(s.min()) >= O.SCALE_MIN for s in scales)               # MinValueConstraint after every step
+    moved = sum(int((a != b).any()) for a, b in zip(scales0, scales))
+    assert moved > 0                                                           # the scales do learn
+    if mode == "nq":
+        # nested-quantization scale gradient is <= 0 -> scales can only grow
+        assert all(bool((b >= a).all()) for a, b in zip(scales0, scales))
+    l, acc = tr.evaluate(x, y)
+    assert np.isfinite(l) and 0.0 <= acc <= 1.0
+
+
+def test_resnet18_like_forward_backward_small_images(dev, tmp_path):
+    from learned_quantization_amd.train import Trainer
+    tr = Trainer("imagenette", "nq", 1e-11, "channelwise", None, device=dev, log_dir=str(tmp_path))
+    x = torch.rand(4, 3, 64, 64, device=dev) * 255.0
+    y = torch.randint(0, 10, (4,), device=dev)
+    p = tr.model(x)
+    assert p.shape == (4, 10) and torch.allclose(p.sum(1), torch.ones(4, device=dev), atol=1e-5)
+    assert np.isfinite(float(tr.step(x, y)))
+    stem = tr.custom_layers[0]
+    assert stem.kernel.grad is not None and stem.nested_q_k_layer.scale.grad is not None
+
+
+def test_export_matches_reference_format(dev, tmp_path):
+    import learned_quantization_amd as lq
+    lq.reset_layer_names()
+    m = lq.build_model("cifar", mode="nq", value=1e-11, seed=1, orientation="channelwise", device=dev)
+    with torch.no_grad():
+        for l in lq.custom_layers_of(m):
+            l.nested_q_k_layer.scale.fill_(0.01)
+            l.nested_q_b_layer.scale.fill_(0.02)
+    sizes = lq.save_compress_parameters(m, str(tmp_path))
+    w = np.load(tmp_path / "weights.npy", allow_pickle=True).item()           # our own file: a pickled dict like the reference's
+    assert "custom_conv2d_layer/W" in w and "custom_conv2d_layer_5/b" in w
+    for l in lq.custom_layers_of(m):
+        k, b = l.kernel.detach().cpu().numpy(), l.b.detach().cpu().numpy()
+        assert w[l.name + "/W"].dtype == np.int8 and w[l.name + "/W"].shape == k.shape      # HWIO, like the reference
+        np.testing.assert_array_equal(w[l.name + "/W"], O.export_int8(k, np.full((1, 1, k.shape[2], 1), 0.01, np.float32)))
+        np.testing.assert_array_equal(w[l.name + "/b"], O.export_int8(b, np.array([0.02], np.float32)))
+    with zipfile.ZipFile(tmp_path / "weights.zip") as z:
+        assert z.namelist() == ["weights.npy"] and z.getinfo("weights.npy").compress_type == zipfile.ZIP_DEFLATED
+    lines = open(tmp_path / "file_sizes.log").read().splitlines()
+    assert lines[0].startswith("Weights size: ") and lines[1].startswith("Compressed weights size: ") and lines[0].endswith(" MB")
+    assert sizes["zip_mb"] < sizes["weights_mb"]
+    sc = np.load(tmp_path / "scales.npz")
+    assert sc["custom_conv2d_layer/W_scale"].shape == (1, 1, 3, 1)
+
+
+def test_tracking_callback_logs(dev, tmp_path):
+    import learned_quantization_amd as lq
+    lq.reset_layer_names()
+    layer = lq.CustomConv2DLayer(seed=1, penalty_threshold=1e-11, orientation="channelwise", initializer=lq.RandomNormal(seed=3),
+                                 filters=8, kernel_size=(3, 3), strides=(1, 1), padding="same", name="n", regularizer=None,
+                                 input_shape=4, device=dev)
+    with torch.no_grad():
+        layer.nested_q_k_layer.scale.fill_(0.01)
+        layer.nested_q_b_layer.scale.fill_(0.02)
+    cb = lq.NestedScaleTrackingCallback(layer, str(tmp_path))
+    cb.on_train_begin()
+    st = cb.on_epoch_end(0)
+    cb.on_epoch_end(1)
+    cb.on_train_end()
+    k, b = layer.kernel.detach().cpu().numpy(), layer.b.detach().cpu().numpy()
+    qk = O.quantized_integers(k, np.full((1, 1, 4, 1), 0.01, np.float32))
+    qb = O.quantized_integers(b, np.array([0.02], np.float32))
+    assert st["unique_k"] == len(np.unique(qk)) and st["unique_b"] == len(np.unique(qb))
+    np.testing.assert_array_equal(st["max_k"].numpy(), np.max(np.abs(qk), axis=1).flatten())   # custom_callbacks.py:98-99
+    assert st["max_b"] == float(np.max(np.abs(qb)))
+    name = "Kernel_custom_conv2d_layer_(3, 3, 4, 8)"
+    text = open(tmp_path / "on_epoch_end" / f"Number_of_unique_{name}.log").read().splitlines()
+    assert text == ["Epoch 0", str(st["unique_k"]), "Epoch 1", str(st["unique_k"])]             # parser format of plot_scripts.py:13-38
+    mx = open(tmp_path / "on_epoch_end" / f"Max_{name}.log").read().splitlines()
+    assert mx[0] == "Epoch 0" and len(mx) == 2 * (1 + 3 * 4 * 8)
+    q_lines = open(tmp_path / "on_train_end" / f"Quantized_{name}_Columnwise-scaler_(1, 1, 4, 1).log").read().splitlines()
+    assert len(q_lines) == k.size and float(q_lines[0]) == qk.flatten()[0]
+    u_lines = open(tmp_path / "on_train_begin" / f"Unique_initial_quantized_{name}_Columnwise-scaler_(1, 1, 4, 1).log").read().splitlines()
+    assert len(u_lines) == len(np.unique(qk)) and ", " in u_lines[0]
+    acc = lq.AccuracyLossTrackingCallBack(str(tmp_path))
+    acc.on_epoch_end(0, {"val_accuracy": 0.5, "val_loss": 1.0, "accuracy": 0.4, "loss": 1.2})
+    assert open(tmp_path / "accuracy" / "val_accuracy.log").read() == "Epoch 0\n0.5\n"
