@@ -64,6 +64,12 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (one graph per buffer set)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the informational extra measurements (N=1 only)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl = RCCL over xGMI (default). "
+                    "'gloo' + --share-gpu rehearses the N>1 code path on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--exchange", choices=["async", "sync"], default="sync",
+                    help="scale-gradient all-reduce: sync (runs on the compute stream: ~10 us/step measured) or async (RCCL side stream + events: ~27 us/step)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (exercises the RCCL path)")
     return ap.parse_args()
 
 
@@ -106,11 +112,24 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    if args.share_gpu:
+        if args.backend == "nccl":
+            raise SystemExit("--share-gpu is a rehearsal mode and needs --backend gloo (RCCL cannot put two ranks on one GPU)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from learned_quantization_amd import _hip
     lib = _hip.load()
@@ -127,7 +146,11 @@ def main():
     else:
         s = torch.tensor([1.0], device=dev)
         outer, G, inner = 1, 1, ELEMS
-    ds = torch.zeros_like(s)
+    # two gradient buffers: the (tiny) scale-gradient all-reduce of step i runs asynchronously on RCCL's
+    # stream and overlaps the kernels of step i+1; a buffer is reused only after its collective completed
+    dss = [torch.zeros_like(s), torch.zeros_like(s)]
+    ds = dss[0]
+    pending = [None, None]
     ws_bytes = lib.lq_workspace_bytes(outer, G, inner)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
@@ -136,35 +159,62 @@ def main():
     px = [t.data_ptr() for t in xs]
     pdy = [t.data_ptr() for t in dys]
     pout = [t.data_ptr() for t in outs]
-    ps, pds, pws = s.data_ptr(), ds.data_ptr(), ws.data_ptr()
+    ps, pws = s.data_ptr(), ws.data_ptr()
+    pdss = [t.data_ptr() for t in dss]
+    pds = pdss[0]
 
     fwd, bwd, fused = lib.lq_fq_forward, lib.lq_fq_scale_grad, lib.lq_fq_fwd_bwd_fused
 
+    avg_op = dist.ReduceOp.AVG if (use_dist and args.backend == "nccl") else None
+
+    def exchange(i):
+        """learned-scale gradient exchange (mode A): mean over ranks, asynchronous."""
+        b = i & 1
+        if args.exchange == "sync":
+            if avg_op is not None:
+                dist.all_reduce(dss[b], op=avg_op)
+            else:
+                dss[b].div_(world)
+                dist.all_reduce(dss[b], op=dist.ReduceOp.SUM)
+        elif avg_op is not None:     # RCCL averages in the collective: no extra kernel on the compute stream
+            pending[b] = dist.all_reduce(dss[b], op=avg_op, async_op=True)
+        else:
+            dss[b].div_(world)
+            pending[b] = dist.all_reduce(dss[b], op=dist.ReduceOp.SUM, async_op=True)
+
     def step(i, ev=None):
         k = i % nsets
+        b = i & 1
+        if use_dist and pending[b] is not None:
+            pending[b].wait()          # stream-level dependency: the buffer's previous collective is done
+            pending[b] = None
         if args.variant == "split":
             if ev:
                 ev[0].record(stream)
             rc = fwd(px[k], ps, pout[k], None, 0, outer, G, inner, sp)
             if ev:
                 ev[1].record(stream)
-            rc |= bwd(px[k], ps, pdy[k], lam, pds, None, pws, ws_bytes, outer, G, inner, sp)
+            rc |= bwd(px[k], ps, pdy[k], lam, pdss[b], None, pws, ws_bytes, outer, G, inner, sp)
             if ev:
                 ev[2].record(stream)
         else:
             if ev:
                 ev[0].record(stream)
-            rc = fused(px[k], ps, pdy[k], lam, pout[k], pds, pws, ws_bytes, outer, G, inner, sp)
+            rc = fused(px[k], ps, pdy[k], lam, pout[k], pdss[b], pws, ws_bytes, outer, G, inner, sp)
             if ev:
                 ev[2].record(stream)
         if rc:
             _hip.check(rc, "bench step")
-        if world > 1:
-            dist.all_reduce(ds, op=dist.ReduceOp.SUM)     # learned-scale gradient exchange (mode A)
+        if use_dist:
+            exchange(i)
 
     def fence():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -189,13 +239,16 @@ def main():
         torch.cuda.synchronize(dev)
 
         def step(i, ev=None):  # noqa: F811
+            if use_dist and pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
             if ev:
                 ev[0].record(stream)
-            graphs[i % nsets].replay()
+            graphs[i % nsets].replay()          # the captured launches write dss[0]
             if ev:
                 ev[2].record(stream)
-            if world > 1:
-                dist.all_reduce(ds, op=dist.ReduceOp.SUM)
+            if use_dist:
+                exchange(0)
 
     for i in range(args.warmup):
         step(i)
@@ -208,7 +261,7 @@ def main():
         step(i, events[i])
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -325,7 +378,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -134,6 +134,11 @@ int lq_penalty_inverse_bwd(const float* s, const float* c_dev, float c_scale, fl
 int lq_scale_adam_step(float* s, const float* ds, float* m, float* v, int64_t n,
                        double lr, double beta1, double beta2, double eps, int64_t step,
                        float min_value, int mode, void* stream);
+/* Capture-safe form: the 1-based step is read from DEVICE memory at execution time (int64), so the launch can
+ * live inside a hipGraph and be replayed while the caller increments the counter on the device.           */
+int lq_scale_adam_step_dev(float* s, const float* ds, float* m, float* v, int64_t n,
+                           double lr, double beta1, double beta2, double eps, const int64_t* step_dev,
+                           float min_value, int mode, void* stream);
 int lq_min_value_project(float* w, int64_t n, float min_value, void* stream);
 
 /* ---- integer-view statistics (callbacks) ----------------------------------------------

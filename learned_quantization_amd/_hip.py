@@ -43,6 +43,7 @@ SIGNATURES = {
     "lq_penalty_inverse_fwd": (_c_int, [_c_p, _c_p, _c_i64, _c_p]),
     "lq_penalty_inverse_bwd": (_c_int, [_c_p, _c_p, _c_f, _c_p, _c_i64, _c_p]),
     "lq_scale_adam_step": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_d, _c_d, _c_d, _c_d, _c_i64, _c_f, _c_int, _c_p]),
+    "lq_scale_adam_step_dev": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_d, _c_d, _c_d, _c_d, _c_p, _c_f, _c_int, _c_p]),
     "lq_min_value_project": (_c_int, [_c_p, _c_i64, _c_f, _c_p]),
     "lq_q_absmax_over_axis": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
 }

@@ -886,6 +886,34 @@ __global__ void k_adam(float* s, const float* ds, float* m, float* v, int64_t n,
     s[i] = w;
 }
 
+// Same update, with the 1-based step read from device memory (hipGraph-capturable: nothing about the
+// step is baked into the launch).  Keras mode forms beta^t in fp32 like tf.pow; torch mode in fp64.
+__global__ void k_adam_dev(float* s, const float* ds, float* m, float* v, int64_t n, float lr, float b1, float b2, double lr_d,
+                           double b1_d, double b2_d, float f0, float f1, float eps, const int64_t* step_dev, float min_value,
+                           int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t step = step_dev[0];
+    const float g = ds[i];
+    float mi = m[i], vi = v[i], w = s[i];
+    mi = mi + (g - mi) * f0;
+    vi = vi + (g * g - vi) * f1;
+    if (mode == LQ_ADAM_KERAS) {
+        const float b1p = powf(b1, (float)step), b2p = powf(b2, (float)step);
+        const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+        w = w - (mi * alpha) / (sqrtf(vi) + eps);
+    } else {
+        const double bc1 = 1.0 - pow(b1_d, (double)step), bc2 = 1.0 - pow(b2_d, (double)step);
+        const float step_size = (float)(lr_d / bc1);
+        const float denom = sqrtf(vi) / (float)sqrt(bc2) + eps;
+        w = w - step_size * (mi / denom);
+    }
+    w = (w < min_value) ? min_value : w;
+    m[i] = mi;
+    v[i] = vi;
+    s[i] = w;
+}
+
 __global__ void k_min_project(float* w, int64_t n, float min_value) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1357,6 +1385,21 @@ int lq_scale_adam_step(float* s, const float* ds, float* m, float* v, int64_t n,
     }
     hipLaunchKernelGGL(k_adam, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, s, ds, m, v, n, f0, f1, f2, (float)eps, f4, min_value, mode);
     return check_hip("adam launch");
+}
+
+int lq_scale_adam_step_dev(float* s, const float* ds, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                           double eps, const int64_t* step_dev, float min_value, int mode, void* stream) {
+    if (n <= 0) return fail(LQ_EINVAL, "lq_scale_adam_step_dev: n must be positive");
+    if (mode != LQ_ADAM_KERAS && mode != LQ_ADAM_TORCH) return fail(LQ_EINVAL, "lq_scale_adam_step_dev: bad mode %d", mode);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(ds);
+    LQ_REQUIRE_PTR(m);
+    LQ_REQUIRE_PTR(v);
+    if (!step_dev || !aligned(step_dev, 8)) return fail(LQ_EINVAL, "lq_scale_adam_step_dev: step_dev must be an 8-byte aligned device pointer");
+    hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, s, ds, m, v, n,
+                       (float)lr, (float)beta1, (float)beta2, lr, beta1, beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
+                       (float)eps, step_dev, min_value, mode);
+    return check_hip("adam (device step) launch");
 }
 
 int lq_min_value_project(float* w, int64_t n, float min_value, void* stream) {

@@ -148,6 +148,23 @@ def scale_adam_step_(scale: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v
                                       _hip.stream_ptr(scale.device)), "lq_scale_adam_step")
 
 
+def scale_adam_step_dev_(scale: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step_dev: torch.Tensor,
+                         lr: float = 1e-4, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-7,
+                         min_value: float = 0.0, mode: str = "keras") -> None:
+    """K6, hipGraph-capturable form: ``step_dev`` is a 1-element int64 device tensor holding the 1-based step."""
+    lib = _hip.load()
+    for name, t in (("scale", scale), ("grad", grad), ("m", m), ("v", v)):
+        _hip.require_device_f32(t, name)
+        if not t.is_contiguous() or t.numel() != scale.numel():
+            raise ValueError(f"{name} must be contiguous with {scale.numel()} elements")
+    if step_dev.dtype != torch.int64 or not step_dev.is_cuda or step_dev.numel() != 1:
+        raise TypeError("step_dev must be a 1-element int64 device tensor")
+    md = {"keras": _hip.LQ_ADAM_KERAS, "torch": _hip.LQ_ADAM_TORCH}[mode]
+    _hip.check(lib.lq_scale_adam_step_dev(_hip.ptr(scale), _hip.ptr(grad), _hip.ptr(m), _hip.ptr(v), scale.numel(),
+                                          lr, beta1, beta2, eps, _hip.ptr(step_dev), float(min_value), md,
+                                          _hip.stream_ptr(scale.device)), "lq_scale_adam_step_dev")
+
+
 # --------------------------------------------------------------------------- autograd ops
 class _NestedQuantFn(torch.autograd.Function):
     """custom_layers.py:49-120 -- forward K1, backward (dy, K2+K3, None)."""

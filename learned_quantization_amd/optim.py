@@ -38,10 +38,14 @@ class ScaleAdam(torch.optim.Optimizer):
     """Adam for the learned scales with the MinValueConstraint projection fused (K6)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-4, betas=(0.9, 0.999),
-                 eps: float = 1e-7, mode: str = "keras"):
+                 eps: float = 1e-7, mode: str = "keras", capturable: bool = False):
+        """``capturable=True`` keeps the step counter on the device (``lq_scale_adam_step_dev``) so that
+        ``step()`` can be recorded into a hipGraph and replayed."""
         if mode not in ("keras", "torch"):
             raise ValueError("mode must be 'keras' or 'torch'")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, mode=mode))
+        self.capturable = capturable
+        self._step_t = None
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -49,6 +53,11 @@ class ScaleAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if self.capturable:
+            if self._step_t is None:
+                dev = self.param_groups[0]["params"][0].device
+                self._step_t = torch.zeros(1, dtype=torch.int64, device=dev)
+            self._step_t += 1                                  # device-side counter: replay-safe
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -62,6 +71,10 @@ class ScaleAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 c = getattr(p, "lq_constraint", None)
                 min_value = float(c.min_value) if c is not None else float("-inf")
-                ops.scale_adam_step_(p.data, p.grad.contiguous(), st["m"], st["v"], st["step"], lr=group["lr"],
-                                     beta1=b1, beta2=b2, eps=group["eps"], min_value=min_value, mode=group["mode"])
+                if self.capturable:
+                    ops.scale_adam_step_dev_(p.data, p.grad.contiguous(), st["m"], st["v"], self._step_t, lr=group["lr"],
+                                             beta1=b1, beta2=b2, eps=group["eps"], min_value=min_value, mode=group["mode"])
+                else:
+                    ops.scale_adam_step_(p.data, p.grad.contiguous(), st["m"], st["v"], st["step"], lr=group["lr"],
+                                         beta1=b1, beta2=b2, eps=group["eps"], min_value=min_value, mode=group["mode"])
         return loss

@@ -45,7 +45,7 @@ def synthetic_batch(config: str, batch: int, device, generator: Optional[torch.G
 
 class Trainer:
     def __init__(self, config="cifar", mode="nq", value=1e-11, orientation="channelwise", loss: Optional[str] = None,
-                 lr=1e-4, seed=42, device=None, ddp_mode="A", log_dir="logs"):
+                 lr=1e-4, seed=42, device=None, ddp_mode="A", log_dir="logs", graph=False):
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         torch.manual_seed(seed)
         L.reset_layer_names()
@@ -60,9 +60,13 @@ class Trainer:
             self.loss_obj = LOSSES[loss](self.custom_layers, value, log_dir)      # custom_loss_terms/experiment.py:436-455
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.dp = DataParallel(self.model, mode=ddp_mode) if self.world > 1 else None
-        self.opt = torch.optim.Adam(non_scale_parameters(self.model), lr=lr, eps=1e-7)   # Keras Adam defaults
-        self.scale_opt = ScaleAdam(scale_parameters(self.model), lr=lr)
+        if graph and self.world > 1:
+            raise ValueError("graph capture of the whole step is single-GPU only (the all-reduce stays eager)")
+        self.opt = torch.optim.Adam(non_scale_parameters(self.model), lr=lr, eps=1e-7, capturable=graph)   # Keras Adam defaults
+        self.scale_opt = ScaleAdam(scale_parameters(self.model), lr=lr, capturable=graph)
         self.regularized = [l for l in self.custom_layers if l.regularizer is not None]
+        self.graph = None
+        self._want_graph = graph
 
     def loss(self, y, p):
         if self.loss_obj is not None:
@@ -89,6 +93,32 @@ class Trainer:
         self.scale_opt.step()
         return loss
 
+    def step_graphed(self, x, y):
+        """The whole training step (forward, loss, backward, both optimizers) as ONE hipGraph launch.
+        The step is launch-bound at these model sizes (hundreds of small kernels); capture removes the
+        host from the loop.  First call: 3 eager warm-up steps on a side stream, then capture."""
+        if self.graph is None:
+            self._x = torch.empty_like(x)
+            self._y = torch.empty_like(y)
+            self._x.copy_(x)
+            self._y.copy_(y)
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self.step(self._x, self._y)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self.graph = torch.cuda.CUDAGraph()
+            self.opt.zero_grad(set_to_none=True)
+            self.scale_opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                self._loss = self.step(self._x, self._y)
+        self._x.copy_(x)
+        self._y.copy_(y)
+        self.graph.replay()
+        return self._loss
+
     @torch.no_grad()
     def evaluate(self, x, y):
         self.model.eval()
@@ -109,6 +139,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--ddp-mode", choices=["A", "B"], default="A")
     ap.add_argument("--export-dir", default=None, help="write the reference's integer export here at the end")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step in a hipGraph (single GPU)")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,17 +154,18 @@ def main(argv=None):
     rank = dist.get_rank() if world > 1 else 0
 
     tr = Trainer(args.config, args.mode, args.value, args.orientation, args.loss, seed=args.seed, device=dev,
-                 ddp_mode=args.ddp_mode)
+                 ddp_mode=args.ddp_mode, graph=args.graph)
+    do_step = tr.step_graphed if args.graph else tr.step
     g = torch.Generator(device=dev).manual_seed(args.seed + rank)
     batches = [synthetic_batch(args.config, args.batch, dev, g) for _ in range(4)]
     for i in range(args.warmup):
-        tr.step(*batches[i % 4])
+        do_step(*batches[i % 4])
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = tr.step(*batches[i % 4])
+        loss = do_step(*batches[i % 4])
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -148,7 +180,8 @@ def main(argv=None):
             "metric": "images/sec end-to-end training step (synthetic data)", "config": args.config, "mode": args.mode,
             "value": world * args.batch * args.steps / dt, "unit": "images/s", "n_gpus": world,
             "ms_per_step": dt / args.steps * 1e3, "per_gpu_batch": args.batch, "orientation": args.orientation,
-            "loss_term": args.loss, "quantized_elements": n_q, "final_loss": float(loss), "ddp_mode": args.ddp_mode}))
+            "loss_term": args.loss, "quantized_elements": n_q, "final_loss": float(loss), "ddp_mode": args.ddp_mode,
+            "hipgraph": bool(args.graph)}))
         if args.export_dir:
             from .export import save_compress_parameters
             print(json.dumps(save_compress_parameters(tr.model, args.export_dir)))

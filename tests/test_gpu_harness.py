@@ -109,3 +109,28 @@ def test_tracking_callback_logs(dev, tmp_path):
     acc = lq.AccuracyLossTrackingCallBack(str(tmp_path))
     acc.on_epoch_end(0, {"val_accuracy": 0.5, "val_loss": 1.0, "accuracy": 0.4, "loss": 1.2})
     assert open(tmp_path / "accuracy" / "val_accuracy.log").read() == "Epoch 0\n0.5\n"
+
+
+def test_capturable_scale_adam_and_graphed_step(dev, tmp_path):
+    """K6 with the step counter on the device == host-step K6; the whole step replays from a hipGraph."""
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(0)
+    p1 = torch.nn.Parameter(torch.full((32,), lq.SCALE_INIT, device=dev))
+    p2 = torch.nn.Parameter(torch.full((32,), lq.SCALE_INIT, device=dev))
+    for p in (p1, p2):
+        p.lq_constraint = lq.MinValueConstraint(lq.SCALE_INIT)
+    o1, o2 = lq.ScaleAdam([p1], lr=1e-4), lq.ScaleAdam([p2], lr=1e-4, capturable=True)
+    for _ in range(5):
+        g = torch.tensor((rng.normal(size=32) * 1e-2).astype(np.float32), device=dev)
+        p1.grad, p2.grad = g.clone(), g.clone()
+        o1.step()
+        o2.step()
+        np.testing.assert_allclose(p2.detach().cpu().numpy(), p1.detach().cpu().numpy(), rtol=1e-6)
+    from learned_quantization_amd.train import Trainer, synthetic_batch
+    tr = Trainer("cifar", "nq", 1e-3, "channelwise", None, device=dev, log_dir=str(tmp_path), graph=True)
+    x, y = synthetic_batch("cifar", 32, dev, torch.Generator(device=dev).manual_seed(0))
+    s0 = tr.custom_layers[0].nested_q_k_layer.scale.detach().clone()
+    losses = [float(tr.step_graphed(x, y)) for _ in range(4)]
+    assert all(np.isfinite(l) for l in losses) and tr.graph is not None
+    s1 = tr.custom_layers[0].nested_q_k_layer.scale.detach()
+    assert bool((s1 >= s0).all()) and float(s1.min()) >= O.SCALE_MIN
