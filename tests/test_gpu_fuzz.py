@@ -1,0 +1,141 @@
+"""Seeded randomized GPU-vs-oracle sweep: shapes, ranks, orientations, scale magnitudes, special values,
+misaligned views -- every op of the C ABI.  Bit-exact on integers / out / max; rtol 1e-5 on float reductions."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lq_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rand_shape(rng):
+    rank = rng.choice([1, 2, 2, 4, 4, 3])
+    if rank == 1:
+        return (int(rng.integers(1, 3000)),)
+    if rank == 2:
+        return (int(rng.integers(1, 400)), int(rng.integers(1, 400)))
+    if rank == 3:
+        return (int(rng.integers(1, 40)), int(rng.integers(1, 40)), int(rng.integers(1, 1500)))
+    return (int(rng.integers(1, 8)), int(rng.integers(1, 8)), int(rng.integers(1, 70)), int(rng.integers(1, 70)))
+
+
+def _rand_case(rng):
+    shape = _rand_shape(rng)
+    orient = "scalar" if len(shape) == 1 else str(rng.choice(["rowwise", "columnwise", "channelwise", "scalar"]))
+    if orient == "channelwise" and len(shape) < 3:
+        orient = "rowwise"
+    mag = float(10.0 ** rng.uniform(-3, 2))
+    P = (rng.normal(0, mag, size=shape)).astype(np.float32)
+    smag = float(10.0 ** rng.uniform(-6, 1)) * mag
+    s = rng.uniform(0.5 * smag, 2 * smag, size=O.scale_shape(shape, orient)).astype(np.float32)
+    dy = (rng.normal(0, 10.0 ** rng.uniform(-6, 0), size=shape)).astype(np.float32)
+    lam = float(rng.choice([0.0, 1e-11, 1e-6, 1e-3, 3e-2, 0.4, 2.0]))
+    kind = rng.integers(0, 6)
+    flat = P.reshape(-1)
+    if kind == 1 and flat.size > 4:
+        flat[rng.integers(0, flat.size, size=max(1, flat.size // 10))] = 0.0          # exact zeros (out == 0 branch)
+    elif kind == 2 and flat.size > 4:
+        flat[rng.integers(0, flat.size, size=3)] = np.float32(1e-42)                    # denormals
+        flat[rng.integers(0, flat.size)] = np.float32(-0.0)
+    elif kind == 3:
+        s = (s * np.float32(2.0 ** rng.integers(-30, 30))).astype(np.float32)          # far-off scales
+    elif kind == 4 and flat.size > 4:
+        s.reshape(-1)[0] = np.float32(np.nextafter(np.float32(2.0), np.float32(1.0)))   # all-ones mantissa -> IEEE path
+    return P, s, dy, lam, orient
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_fuzz_forward_backward(dev):
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(20240229)
+    for it in range(160):
+        P, s, dy, lam, orient = _rand_case(rng)
+        tag = f"case {it}: shape={P.shape} orient={orient} lam={lam}"
+        with np.errstate(all="ignore"):
+            q_o, out_o = O.fq_forward(P, s)
+            _, ds_o, im = O.nq_backward(P, s, lam, dy, return_intermediates=True)
+        out, q = lq.fq_forward(_t(P, dev), _t(s, dev), q_dtype=torch.float32)
+        np.testing.assert_array_equal(q.cpu().numpy(), q_o, err_msg=tag)
+        np.testing.assert_array_equal(out.cpu().numpy(), out_o, err_msg=tag)
+        ds, parts = lq.fq_scale_grad(_t(P, dev), _t(s, dev), _t(dy, dev), lam, return_parts=True)
+        np.testing.assert_array_equal(parts[0].cpu().numpy(), np.asarray(im["maxvalue"], np.float32).reshape(-1), err_msg=tag)
+        np.testing.assert_allclose(ds.cpu().numpy(), ds_o, rtol=RTOL, atol=1e-30, equal_nan=True, err_msg=tag)
+        out2, ds2 = lq.fq_fwd_bwd_fused(_t(P, dev), _t(s, dev), _t(dy, dev), lam)
+        np.testing.assert_array_equal(out2.cpu().numpy(), out_o, err_msg=tag)
+        np.testing.assert_array_equal(ds2.cpu().numpy(), ds.cpu().numpy(), err_msg=tag)
+
+
+def test_fuzz_misaligned_views(dev):
+    """Storage offsets of 1..3 floats break 16-byte alignment: the scalar kernels must give identical results."""
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(7)
+    for it in range(24):
+        rows, cols = int(rng.integers(1, 6)), int(rng.integers(1024, 6000))
+        off = int(rng.integers(1, 4))
+        base_p = torch.from_numpy(rng.normal(0, 0.05, size=rows * cols + off).astype(np.float32)).to(dev)
+        base_d = torch.from_numpy(rng.normal(0, 1e-3, size=rows * cols + off).astype(np.float32)).to(dev)
+        P, dy = base_p[off:].view(rows, cols), base_d[off:].view(rows, cols)
+        assert P.data_ptr() % 16 != 0 and P.is_contiguous()
+        s = torch.from_numpy(rng.uniform(1e-3, 1e-2, size=(rows, 1)).astype(np.float32)).to(dev)
+        q_o, out_o = O.fq_forward(P.cpu().numpy(), s.cpu().numpy())
+        _, ds_o = O.nq_backward(P.cpu().numpy(), s.cpu().numpy(), 1e-3, dy.cpu().numpy())
+        np.testing.assert_array_equal(lq.fq_forward(P, s).cpu().numpy(), out_o)
+        np.testing.assert_allclose(lq.fq_scale_grad(P, s, dy, 1e-3).cpu().numpy(), ds_o, rtol=RTOL)
+        out2, ds2 = lq.fq_fwd_bwd_fused(P, s, dy, 1e-3)
+        np.testing.assert_array_equal(out2.cpu().numpy(), out_o)
+
+
+def test_fuzz_penalty_terms(dev):
+    import learned_quantization_amd as lq
+    from oracle import lq_oracle_f64 as O64
+    rng = np.random.default_rng(99)
+    for it in range(60):
+        P, s, _, _, orient = _rand_case(rng)
+        s = np.abs(s) + np.float32(1e-12)
+        desc = O.group_descriptor(P.shape, s.shape)
+        Pt = torch.tensor(P, device=dev, requires_grad=True)
+        st = torch.tensor(s, device=dev, requires_grad=True)
+        tag = f"case {it}: shape={P.shape} orient={orient}"
+        with np.errstate(all="ignore"):
+            mb = lq.maxbin_term(Pt, st)
+            assert float(mb) == pytest.approx(O64.maxbin_term(P, s, *desc), rel=2e-5, abs=1e-30), tag
+            df = lq.difference_term(Pt, st)
+            assert float(df) == pytest.approx(O64.difference_term(P, s, *desc), rel=2e-5, abs=1e-30), tag
+            iv = lq.inverse_term(st)
+            assert float(iv) == pytest.approx(O64.inverse_term(s), rel=2e-5), tag
+            (mb * 0.3).backward()
+            dp, ds = O.maxbin_term_grads(P, s, 0.3)
+            np.testing.assert_allclose(Pt.grad.cpu().numpy(), dp, rtol=1e-5, atol=1e-30, err_msg=tag)
+            np.testing.assert_allclose(st.grad.cpu().numpy(), ds, rtol=1e-4, atol=1e-30, err_msg=tag)
+            Pt.grad = None
+            st.grad = None
+            (df * 0.7).backward()
+            dp, ds = O.difference_term_grads(P, s, 0.7)
+            np.testing.assert_allclose(Pt.grad.cpu().numpy(), dp, rtol=1e-5, atol=1e-30, err_msg=tag)
+            scale_tol = np.abs(ds).max() * 1e-4 + 1e-30
+            np.testing.assert_allclose(st.grad.cpu().numpy(), ds, rtol=2e-3, atol=scale_tol, err_msg=tag)
+
+
+def test_inf_and_huge_values_take_the_ieee_path(dev):
+    import learned_quantization_amd as lq
+    P = np.array([[np.inf, -np.inf, 3e38, -3e38, 1e-45, -1e-45, 0.0, -0.0] * 160], np.float32)    # one row of 1280
+    for sv in (0.5, 1e-3, 7.0, 3e-20, 3e20):
+        s = np.array([[sv]], np.float32)
+        with np.errstate(all="ignore"):
+            q_o, out_o = O.fq_forward(P, s)
+        out, q = lq.fq_forward(_t(P, dev), _t(s, dev), q_dtype=torch.float32)
+        np.testing.assert_array_equal(q.cpu().numpy(), q_o)
+        np.testing.assert_array_equal(out.cpu().numpy(), out_o)
+        # sign of zero is preserved exactly (bit pattern), like IEEE division
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), out_o.view(np.uint32))
