@@ -15,7 +15,8 @@ from typing import Dict, Optional, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblq_hip.so")
+# LQ_HIP_LIB overrides the library path (development: experiment builds of the same ABI)
+LIB_PATH = os.environ.get("LQ_HIP_LIB") or os.path.join(_HERE, "csrc", "liblq_hip.so")
 
 LQ_Q_NONE, LQ_Q_F32, LQ_Q_I32, LQ_Q_I8 = 0, 1, 2, 3
 LQ_ADAM_KERAS, LQ_ADAM_TORCH = 0, 1

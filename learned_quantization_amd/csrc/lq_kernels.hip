@@ -22,6 +22,7 @@
 //   constraint        custom_layers.py:35-46
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -76,7 +77,7 @@ struct AccT {
     TC c;
 };
 using Acc = AccT<uint32_t, float>;
-using AccW = AccT<unsigned long long, double>;
+using AccW = AccT<double, double>;   // finalize: count and sum in f64 (counts are exact below 2^53)
 
 enum OpKind {
     OP_FWD = 0,        // K1
@@ -746,7 +747,7 @@ struct FinT<OP_BWD> {
     __device__ static void emit(const Params& p, const FinGeom& f, int64_t g, const AccW& a) {
         const float maxq = __uint_as_float(a.a);
         float mean;
-        if (a.b == 0ull) {
+        if (a.b == 0.0) {
             mean = -1.0f * fabsf(tanhf(p.lam));                 // custom_layers.py:79 / :105
         } else {
             mean = (float)(a.c / f.count);                      // :87 / :113
@@ -766,7 +767,7 @@ template <>
 struct FinT<OP_MAXBIN_FWD> {
     __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
         f.o0[g] = __uint_as_float(a.a);
-        f.o2[g] = (uint32_t)(a.b > 0xffffffffull ? 0xffffffffull : a.b);
+        f.o2[g] = (uint32_t)(a.b > 4294967295.0 ? 4294967295.0 : a.b);
     }
 };
 
@@ -788,24 +789,86 @@ template <class O>
 __device__ __forceinline__ AccW load_partial(const Params& p, int64_t idx) {
     AccW w;
     w.a = p.pa[idx];
-    w.b = p.pb[idx];
+    w.b = (double)p.pb[idx];
     w.c = (double)p.pc[idx];
     return w;
 }
 
-// One block of BS threads per group.
+// DPP reduction of the wide standard accumulator (max, add, add); same lane pattern as dpp_wave_reduce.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)u);
+    const uint32_t hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(u >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_step_w(AccW& acc) {
+    const uint32_t a = dpp_u32<CTRL, ROW_MASK>(0u, acc.a);
+    const double b = dpp_f64<CTRL, ROW_MASK>(acc.b);
+    const double c = dpp_f64<CTRL, ROW_MASK>(acc.c);
+    acc.a = a > acc.a ? a : acc.a;
+    acc.b += b;
+    acc.c += c;
+}
+__device__ __forceinline__ void dpp_row_reduce_w(AccW& acc) {
+    dpp_step_w<0xB1, 0xf>(acc);
+    dpp_step_w<0x4E, 0xf>(acc);
+    dpp_step_w<0x141, 0xf>(acc);
+    dpp_step_w<0x140, 0xf>(acc);
+}
+
+// One block of BS threads per group.  Index arithmetic is 32-bit whenever the partial count allows (a 64-bit
+// division per loaded partial used to dominate this kernel).
 template <int OP, int BS>
 __global__ __launch_bounds__(BS) void k_finalize_block(Params p, FinGeom f) {
     using O = OpT<OP>;
     const int64_t g = blockIdx.x;
     const int64_t n = f.n1 * f.n2;
+    const int64_t gbase = g * f.gstride;
     AccW acc = O::template init<AccW>();
-    for (int64_t k = threadIdx.x; k < n; k += BS) {
-        const int64_t i1 = k / f.n2, i2 = k - i1 * f.n2;
-        O::merge(acc, load_partial<O>(p, g * f.gstride + i1 * f.stride1 + i2));
+    if (n < 0x7fffffffll) {
+        const uint32_t n32 = (uint32_t)n, n2 = (uint32_t)f.n2;
+        for (uint32_t k = threadIdx.x; k < n32; k += BS) {
+            const uint32_t i1 = k / n2, i2 = k - i1 * n2;
+            O::merge(acc, load_partial<O>(p, gbase + (int64_t)i1 * f.stride1 + i2));
+        }
+    } else {
+        for (int64_t k = threadIdx.x; k < n; k += BS) {
+            const int64_t i1 = k / f.n2, i2 = k - i1 * f.n2;
+            O::merge(acc, load_partial<O>(p, gbase + i1 * f.stride1 + i2));
+        }
     }
-    block_reduce<O, AccW, BS>(acc);
-    if (threadIdx.x == 0) FinT<OP>::emit(p, f, g, acc);
+    if constexpr (O::kStdMerge) {
+        constexpr int NW = BS / 64;
+        __shared__ uint32_t sa[NW];
+        __shared__ double sb[NW], sc[NW];
+        dpp_row_reduce_w(acc);
+        dpp_step_w<0x142, 0xa>(acc);
+        dpp_step_w<0x143, 0xc>(acc);
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        if (NW > 1) {
+            if (lane == 63) {
+                sa[wid] = acc.a;
+                sb[wid] = acc.b;
+                sc[wid] = acc.c;
+            }
+            __syncthreads();
+            if (wid == 0) {
+                AccW r;
+                r.a = lane < NW ? sa[lane] : 0u;
+                r.b = lane < NW ? sb[lane] : 0.0;
+                r.c = lane < NW ? sc[lane] : 0.0;
+                dpp_row_reduce_w(r);
+                if (lane == 0) FinT<OP>::emit(p, f, g, r);
+            }
+        } else if (lane == 63) {
+            FinT<OP>::emit(p, f, g, acc);
+        }
+    } else {
+        block_reduce<O, AccW, BS>(acc);
+        if (threadIdx.x == 0) FinT<OP>::emit(p, f, g, acc);
+    }
 }
 
 // One thread per group (few partials per group, possibly very many groups).
@@ -1010,7 +1073,13 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner) {
         pl.L = L;
         if (L >= 1024) {
             pl.mode = MODE_ROW_BIG;
-            pl.bs = L >= 4096 ? 1024 : (L >= 2048 ? 512 : 256);
+            // 512 threads: measured best on MI355X (BENCH bwd 44.9 us vs 53.6 us at 1024 -- fewer waves held at the
+            // closing barrier -- and vs 48.4 us at 256; the forward is insensitive)
+            pl.bs = L >= 2048 ? 512 : 256;
+            if (const char* e = getenv("LQ_TUNE_BS")) {   // development knob (tools/): force the streaming block size
+                const int v = atoi(e);
+                if ((v == 256 || v == 512 || v == 1024) && L >= v * 4) pl.bs = v;
+            }
             pl.CH = pl.bs * 4;
             pl.nc = ceil_div(L, pl.CH);
         } else {
@@ -1087,7 +1156,7 @@ static int launch_traverse(const Plan& pl, const Params& p, hipStream_t st) {
         const int64_t outer_f = pl.R / p.G;
         const int grid3d = (p.G <= 65535 && outer_f <= 65535 && pl.R == outer_f * p.G) ? 1 : 0;
         const dim3 grid = grid3d ? dim3((unsigned)pl.nc, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)units);
-        const bool nt = vec && pl.bs == 1024 && (double)pl.R * (double)pl.L * 4.0 >= (double)kNtBytes;
+        const bool nt = vec && (double)pl.R * (double)pl.L * 4.0 >= (double)kNtBytes;
 #define LQ_LAUNCH_STREAM(VEC_, BS_, NT_) \
         hipLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_>), grid, dim3(BS_), 0, st, p, pl.L, pl.nc, grid3d)
         if (vec) {
@@ -1095,9 +1164,11 @@ static int launch_traverse(const Plan& pl, const Params& p, hipStream_t st) {
                 if (nt) LQ_LAUNCH_STREAM(4, 1024, 1);
                 else LQ_LAUNCH_STREAM(4, 1024, 0);
             } else if (pl.bs == 512) {
-                LQ_LAUNCH_STREAM(4, 512, 0);
+                if (nt) LQ_LAUNCH_STREAM(4, 512, 1);
+                else LQ_LAUNCH_STREAM(4, 512, 0);
             } else {
-                LQ_LAUNCH_STREAM(4, 256, 0);
+                if (nt) LQ_LAUNCH_STREAM(4, 256, 1);
+                else LQ_LAUNCH_STREAM(4, 256, 0);
             }
         } else {
             if (pl.bs == 1024) LQ_LAUNCH_STREAM(1, 1024, 0);
