@@ -152,6 +152,42 @@ int lq_q_absmax_over_axis(const float* P, const float* s, float* result,
                           int64_t pre, int64_t n_axis, int64_t post,
                           int64_t outer, int64_t G, int64_t inner, void* stream);
 
+/* ---- multi-tensor batch -----------------------------------------------------------------
+ * A training step fake-quantises every custom layer's kernel and bias (4 / 12 / 40 tensors in the
+ * reference's MNIST / CIFAR-10 / Imagenette models); one by one they are pure launch latency.
+ * An lq_batch is a device-resident table of per-tensor tasks built ONCE from stable pointers:
+ *   lq_batch_forward     = lq_fq_forward of every tensor in ONE launch                   (custom_layers.py:55-60)
+ *   lq_batch_scale_grad  = lq_fq_scale_grad of every tensor with a finite lambda in TWO  (custom_layers.py:62-118)
+ *                          launches; `dy` (optional, [n] device pointers, indexed like the descriptors)
+ *                          overrides the descriptors' dy -- the upstream gradients move every step
+ *   lq_batch_scale_adam  = lq_scale_adam_step(_dev) of every scale with Adam state in ONE launch
+ * Results are bit-identical to the single-tensor entry points for tensors below 4 M elements (same device
+ * code and reduction geometry); larger tensors differ only by fp32 summation order (~1e-7 relative).
+ * lq_batch_create/destroy allocate/free the table (hipMalloc; not stream-ordered, never inside a capture);
+ * the other calls only enqueue.  lambda = NaN marks an STE-only tensor (custom_loss_terms variant).        */
+typedef struct lq_tensor_desc {
+    const float* P;      /* parameter, contiguous fp32                          */
+    const float* s;      /* scale [G]                                            */
+    const float* dy;     /* default upstream gradient (may be NULL)              */
+    float* out;          /* fake-quantised output                                */
+    float* ds;           /* scale gradient [G] (required when lambda is finite)  */
+    float* m;            /* Adam first moment of the scale [G] or NULL           */
+    float* v;            /* Adam second moment of the scale [G] or NULL          */
+    int64_t outer, G, inner;
+    float lambda;        /* penalty_threshold, or NaN for STE-only               */
+    float min_value;     /* MinValueConstraint bound used by lq_batch_scale_adam */
+} lq_tensor_desc;
+
+typedef struct lq_batch lq_batch;
+
+int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out);
+int lq_batch_destroy(lq_batch* batch);
+size_t lq_batch_workspace_bytes(const lq_batch* batch);
+int lq_batch_forward(const lq_batch* batch, void* stream);
+int lq_batch_scale_grad(const lq_batch* batch, const float* const* dy, void* ws, size_t ws_bytes, void* stream);
+int lq_batch_scale_adam(const lq_batch* batch, double lr, double beta1, double beta2, double eps, int64_t step,
+                        const int64_t* step_dev, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ from .ops import (difference_term, fq_forward, fq_fwd_bwd_fused, fq_scale_grad, 
                   my_custom_gradient, q_absmax_over_axis, quantized_integers)
 from .optim import ScaleAdam, apply_constraints, non_scale_parameters, scale_parameters
 from .ddp import DataParallel, GradBucket
+from .batch import BatchedScaleAdam, FakeQuantBatch
 from .models import CIFARCNN, MNISTDense, ResNet18Like, build_model
 from .export import save_compress_parameters
 from .tracking import AccuracyLossTrackingCallBack, NestedScaleTrackingCallback

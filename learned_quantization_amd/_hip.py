@@ -49,6 +49,23 @@ SIGNATURES = {
     "lq_q_absmax_over_axis": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
 }
 
+
+
+class TensorDesc(ctypes.Structure):
+    """lq_tensor_desc of include/lq_hip.h."""
+    _fields_ = [("P", _c_p), ("s", _c_p), ("dy", _c_p), ("out", _c_p), ("ds", _c_p), ("m", _c_p), ("v", _c_p),
+                ("outer", _c_i64), ("G", _c_i64), ("inner", _c_i64), ("lambda_", _c_f), ("min_value", _c_f)]
+
+
+SIGNATURES.update({
+    "lq_batch_create": (_c_int, [ctypes.POINTER(TensorDesc), _c_int, ctypes.POINTER(_c_p)]),
+    "lq_batch_destroy": (_c_int, [_c_p]),
+    "lq_batch_workspace_bytes": (_c_sz, [_c_p]),
+    "lq_batch_forward": (_c_int, [_c_p, _c_p]),
+    "lq_batch_scale_grad": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
+    "lq_batch_scale_adam": (_c_int, [_c_p, _c_d, _c_d, _c_d, _c_d, _c_i64, _c_p, _c_int, _c_p]),
+})
+
 _lib: Optional[ctypes.CDLL] = None
 _lock = threading.Lock()
 

@@ -1,0 +1,186 @@
+"""Multi-tensor batching of the per-step fake-quant work (SURVEY f-4) on top of ``lq_batch_*``.
+
+A training step of the reference quantises every custom layer's kernel AND bias through its own
+``my_custom_gradient`` call (custom_layers.py:263-268, 338-350): 4 / 12 / 40 tiny ops forward and as many
+backward for the MNIST / CIFAR-10 / Imagenette models.  None of them depends on an activation, so
+
+  * ``FakeQuantBatch.quantize_all()`` runs ALL forwards in one launch before the model forward and hands each
+    layer its quantised tensors;
+  * its autograd node receives ALL upstream gradients at the end of the backward pass and computes every scale
+    gradient in two launches (traversal + finalize), writing ``scale.grad`` directly (no per-scale
+    accumulate kernels) and passing ``dy`` through unchanged as ``∂P`` (STE, custom_layers.py:118);
+  * ``BatchedScaleAdam.step()`` updates every scale (Adam + MinValueConstraint, custom_layers.py:158) in one launch.
+
+Semantics per tensor are those of the single-tensor ops (same device code; results bit-identical).
+Gradient accumulation across several backward passes is not supported in this mode (``scale.grad`` is
+overwritten each backward), which matches the reference's one-backward-per-step training loop.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+
+from . import _hip
+from .descriptor import group_descriptor
+from .layers import CustomDenseLayer, _ConvBase, custom_layers_of
+
+
+class _Entry:
+    __slots__ = ("layer", "slot", "param", "nested", "out", "ds", "m", "v", "desc")
+
+
+class FakeQuantBatch:
+    def __init__(self, model_or_layers, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-7, mode: str = "keras"):
+        layers = custom_layers_of(model_or_layers) if isinstance(model_or_layers, torch.nn.Module) else list(model_or_layers)
+        self.layers = layers
+        self.entries: List[_Entry] = []
+        for layer in layers:
+            if isinstance(layer, _ConvBase):
+                pairs = [(0, layer.kernel, layer.nested_q_k_layer)]
+                if layer._has_bias:
+                    pairs.append((1, layer.b, layer.nested_q_b_layer))
+            elif isinstance(layer, CustomDenseLayer):
+                pairs = [(0, layer.W, layer.nested_q_w_layer), (1, layer.b, layer.nested_q_b_layer)]
+            else:
+                raise TypeError(f"not a custom layer: {type(layer).__name__}")
+            for slot, param, nested in pairs:
+                e = _Entry()
+                e.layer, e.slot, e.param, e.nested = layer, slot, param, nested
+                _hip.require_device_f32(param.data, "parameter")
+                _hip.require_device_f32(nested.scale.data, "scale")
+                if not param.data.is_contiguous():
+                    raise ValueError("parameters must be contiguous")
+                e.out = torch.empty_like(param.data)
+                # write straight into an existing gradient buffer (e.g. a DataParallel bucket view) when there is one
+                g = nested.scale.grad
+                e.ds = g if (g is not None and g.is_contiguous()) else torch.zeros_like(nested.scale.data)
+                e.m = torch.zeros_like(nested.scale.data)
+                e.v = torch.zeros_like(nested.scale.data)
+                e.desc = group_descriptor(tuple(param.shape), tuple(nested.scale.shape))
+                self.entries.append(e)
+        if not self.entries:
+            raise ValueError("no custom layers")
+        self.device = self.entries[0].param.device
+        lib = _hip.load()
+        n = len(self.entries)
+        arr = (_hip.TensorDesc * n)()
+        for i, e in enumerate(self.entries):
+            lam = e.nested.penalty_threshold
+            c = getattr(e.nested.scale, "lq_constraint", None)
+            arr[i] = _hip.TensorDesc(e.param.data_ptr(), e.nested.scale.data_ptr(), None, e.out.data_ptr(), e.ds.data_ptr(),
+                                     e.m.data_ptr(), e.v.data_ptr(), e.desc[0], e.desc[1], e.desc[2],
+                                     float("nan") if lam is None else float(lam),
+                                     float(c.min_value) if c is not None else float("-inf"))
+        handle = ctypes.c_void_p()
+        _hip.check(lib.lq_batch_create(arr, n, ctypes.byref(handle)), "lq_batch_create")
+        self._handle = handle
+        self._ptrs = (ctypes.c_void_p * n)()
+        self.ws = torch.empty(lib.lq_batch_workspace_bytes(handle), dtype=torch.uint8, device=self.device)
+        self.hyper = dict(lr=lr, betas=betas, eps=eps, mode=mode)
+        self._data_ptrs = [(e.param.data_ptr(), e.nested.scale.data_ptr()) for e in self.entries]
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                _hip.load().lq_batch_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def _check_pointers(self):
+        for e, (pp, sp) in zip(self.entries, self._data_ptrs):
+            if e.param.data_ptr() != pp or e.nested.scale.data_ptr() != sp:
+                raise RuntimeError("a parameter or scale was re-allocated after the batch was built "
+                                   "(e.g. model.to(device)); rebuild the FakeQuantBatch")
+
+    # ------------------------------------------------------------------ forward
+    def quantize_all(self):
+        """One launch: fake-quantise every kernel/bias; layers pick the results up in their next call."""
+        self._check_pointers()
+        flat = []
+        for e in self.entries:
+            flat.append(e.param)
+            flat.append(e.nested.scale)
+        outs = _BatchFn.apply(self, *flat)
+        per_layer = {}
+        for e, o in zip(self.entries, outs):
+            per_layer.setdefault(id(e.layer), [e.layer, None, None])[1 + e.slot] = o
+        for layer, qk, qb in per_layer.values():
+            layer._q_pre = (qk, qb)
+        return outs
+
+    # ------------------------------------------------------------------ optimizer
+    def scale_adam_step(self, step: Optional[int] = None, step_dev: Optional[torch.Tensor] = None):
+        lib = _hip.load()
+        h = self.hyper
+        md = {"keras": _hip.LQ_ADAM_KERAS, "torch": _hip.LQ_ADAM_TORCH}[h["mode"]]
+        _hip.check(lib.lq_batch_scale_adam(self._handle, h["lr"], h["betas"][0], h["betas"][1], h["eps"],
+                                           int(step or 0), _hip.ptr(step_dev), md, _hip.stream_ptr(self.device)),
+                   "lq_batch_scale_adam")
+
+
+class _BatchFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, batch: FakeQuantBatch, *tensors):
+        lib = _hip.load()
+        _hip.check(lib.lq_batch_forward(batch._handle, _hip.stream_ptr(batch.device)), "lq_batch_forward")
+        ctx.batch = batch
+        return tuple(e.out.detach() for e in batch.entries)      # fresh tensor objects over the static buffers
+
+    @staticmethod
+    def backward(ctx, *dys):
+        batch: FakeQuantBatch = ctx.batch
+        lib = _hip.load()
+        keep = []
+        for i, (e, d) in enumerate(zip(batch.entries, dys)):
+            if d is None:
+                d = torch.zeros_like(e.out)
+            d = _hip.require_device_f32(d, "dy")
+            keep.append(d)
+            batch._ptrs[i] = d.data_ptr()
+        _hip.check(lib.lq_batch_scale_grad(batch._handle, batch._ptrs, _hip.ptr(batch.ws), batch.ws.numel(),
+                                           _hip.stream_ptr(batch.device)), "lq_batch_scale_grad")
+        grads = [None]
+        for e, d in zip(batch.entries, keep):
+            grads.append(d)                                        # dP is dy itself (custom_layers.py:118)
+            if e.nested.penalty_threshold is not None:
+                e.nested.scale.grad = e.ds                         # written in place by the kernel: no accumulate launch
+                grads.append(None)
+            else:
+                grads.append(None)                                 # STE-only: zeros_like(scale) (CL custom_layers.py:62)
+        return tuple(grads)
+
+
+class BatchedScaleAdam:
+    """Optimizer facade over ``FakeQuantBatch.scale_adam_step`` (K6 for every scale in one launch)."""
+
+    def __init__(self, batch: FakeQuantBatch, capturable: bool = False):
+        self.batch = batch
+        self.capturable = capturable
+        self._step = 0
+        self._step_t = torch.zeros(1, dtype=torch.int64, device=batch.device) if capturable else None
+        self.param_groups = [{"params": [e.nested.scale for e in batch.entries]}]
+
+    def zero_grad(self, set_to_none: bool = True):
+        for e in self.batch.entries:
+            e.nested.scale.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        # only scales that actually received a gradient this step are updated by Adam in the reference too; with the
+        # nested-quantization op every scale does.  STE-only scales are updated from the loss-term gradients.
+        for e in self.batch.entries:
+            g = e.nested.scale.grad
+            if g is None:
+                e.ds.zero_()
+            elif g.data_ptr() != e.ds.data_ptr():
+                e.ds.copy_(g)                                      # loss-term gradients arrive in autograd-owned tensors
+        if self.capturable:
+            self._step_t += 1
+            self.batch.scale_adam_step(step_dev=self._step_t)
+        else:
+            self._step += 1
+            self.batch.scale_adam_step(step=self._step)

@@ -27,6 +27,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <new>
+#include <vector>
+
 #include "lq_hip.h"
 
 namespace lq {
@@ -589,20 +592,9 @@ __device__ __forceinline__ void store4(float* p, const float4& v) {
 }
 
 template <int OP, int VEC, int BS, int NT>
-__global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params p, int64_t L, int64_t nc, int grid3d) {
+__device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int64_t nc, int64_t row, int64_t ck, int64_t g) {
     using O = OpT<OP>;
     constexpr int CH = BS * 4;
-    int64_t row, ck, g;
-    if (grid3d) {
-        ck = blockIdx.x;
-        g = blockIdx.y;
-        row = (int64_t)blockIdx.z * p.G + g;
-    } else {
-        const int64_t unit = blockIdx.x;
-        row = unit / nc;
-        ck = unit - row * nc;
-        g = row % p.G;
-    }
     const int64_t base = row * L + ck * (int64_t)CH;
     const int64_t rem = L - ck * (int64_t)CH;
     const int len = rem < (int64_t)CH ? (int)rem : CH;
@@ -671,17 +663,33 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params 
     }
 }
 
+template <int OP, int VEC, int BS, int NT>
+__global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params p, int64_t L, int64_t nc, int grid3d) {
+    int64_t row, ck, g;
+    if (grid3d) {
+        ck = blockIdx.x;
+        g = blockIdx.y;
+        row = (int64_t)blockIdx.z * p.G + g;
+    } else {
+        const int64_t unit = blockIdx.x;
+        row = unit / nc;
+        ck = unit - row * nc;
+        g = row % p.G;
+    }
+    row_stream_body<OP, VEC, BS, NT>(p, L, nc, row, ck, g);
+}
+
 // ------------------------------------------------------------------------------------------
 //  Traversal 2 -- "row small": rows of length L < 1024.  A team of 2^lpr_log2 lanes (<= 64,
 //  inside one wave) owns a row; 256 >> lpr_log2 rows per block; one partial per row.
 // ------------------------------------------------------------------------------------------
 template <int OP>
-__global__ __launch_bounds__(kBlock) void k_row_small(Params p, int64_t R, int L, int lpr_log2) {
+__device__ __forceinline__ void row_small_body(const Params& p, int64_t R, int L, int lpr_log2, int64_t blk) {
     using O = OpT<OP>;
     const int lpr = 1 << lpr_log2;
     const int team = (int)threadIdx.x >> lpr_log2;
     const int lane = (int)threadIdx.x & (lpr - 1);
-    const int64_t row = (int64_t)blockIdx.x * (kBlock >> lpr_log2) + team;
+    const int64_t row = blk * (kBlock >> lpr_log2) + team;
     const bool valid = row < R;
     Acc acc = O::template init<Acc>();
     if (valid) {
@@ -701,16 +709,20 @@ __global__ __launch_bounds__(kBlock) void k_row_small(Params p, int64_t R, int L
     }
 }
 
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_row_small(Params p, int64_t R, int L, int lpr_log2) {
+    row_small_body<OP>(p, R, L, lpr_log2, (int64_t)blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------
 //  Traversal 3 -- "column": inner < 16 and outer > 1.  The tensor is a matrix [outer][C],
 //  C = G*inner; a thread owns a column (coalesced across the wave) and walks a slice of rows.
 // ------------------------------------------------------------------------------------------
 template <int OP>
-__global__ __launch_bounds__(kBlock) void k_col(Params p, int64_t C, int64_t rps) {
+__device__ __forceinline__ void col_body(const Params& p, int64_t C, int64_t rps, int64_t bx, int64_t y) {
     using O = OpT<OP>;
-    const int64_t col = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t col = bx * kBlock + threadIdx.x;
     if (col >= C) return;   // no block-level synchronisation below
-    const int64_t y = blockIdx.y;
     const Ctx ctx = O::ctx(p, col / p.inner);
     const int64_t r0 = y * rps;
     const int64_t r1 = (r0 + rps < p.outer) ? r0 + rps : p.outer;
@@ -724,6 +736,11 @@ __global__ __launch_bounds__(kBlock) void k_col(Params p, int64_t C, int64_t rps
         if (O::kStore) p.out[i] = v;
     }
     if (O::kReduce) write_partial(p, y * C + col, acc);
+}
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_col(Params p, int64_t C, int64_t rps) {
+    col_body<OP>(p, C, rps, (int64_t)blockIdx.x, (int64_t)blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -821,9 +838,8 @@ __device__ __forceinline__ void dpp_row_reduce_w(AccW& acc) {
 // One block of BS threads per group.  Index arithmetic is 32-bit whenever the partial count allows (a 64-bit
 // division per loaded partial used to dominate this kernel).
 template <int OP, int BS>
-__global__ __launch_bounds__(BS) void k_finalize_block(Params p, FinGeom f) {
+__device__ __forceinline__ void finalize_block_body(const Params& p, const FinGeom& f, int64_t g) {
     using O = OpT<OP>;
-    const int64_t g = blockIdx.x;
     const int64_t n = f.n1 * f.n2;
     const int64_t gbase = g * f.gstride;
     AccW acc = O::template init<AccW>();
@@ -869,6 +885,11 @@ __global__ __launch_bounds__(BS) void k_finalize_block(Params p, FinGeom f) {
         block_reduce<O, AccW, BS>(acc);
         if (threadIdx.x == 0) FinT<OP>::emit(p, f, g, acc);
     }
+}
+
+template <int OP, int BS>
+__global__ __launch_bounds__(BS) void k_finalize_block(Params p, FinGeom f) {
+    finalize_block_body<OP, BS>(p, f, (int64_t)blockIdx.x);
 }
 
 // One thread per group (few partials per group, possibly very many groups).
@@ -1009,6 +1030,131 @@ __global__ void k_q_absmax_axis(const float* P, const float* s, float* result, i
 }
 
 // ------------------------------------------------------------------------------------------
+//  Multi-tensor batch (SURVEY f-4): the 4 / 12 / 40 weight-sized tensors a training step fake-quantises
+//  are latency-bound one by one (each launch costs more than its work).  A batch is a device-resident
+//  table of tasks; ONE launch covers every tensor's traversal (each 256-thread block finds its task by
+//  binary search over the block prefix) and ONE launch finalizes every group of every tensor.  The per-
+//  tensor code is exactly the single-tensor traversal bodies above, so results are bit-identical.
+// ------------------------------------------------------------------------------------------
+struct Task {
+    Params p;                 // pa/pb/pc are rebound to the batch workspace inside the kernel
+    float* ds;                // scale gradient output [G]
+    int mode, vec, lpr_log2, pad0;
+    int64_t R, L, nc;         // row modes (block size 256)
+    int64_t C, rps, nbx;      // column mode
+    int64_t np_pad;           // padded partial count; this task's workspace slice is 3 * np_pad words
+    int64_t ws_off;           // offset of the slice in uint32 words
+    int64_t gstride, n1, stride1, n2;   // finalize geometry
+    double count;             // elements per group
+    uint32_t first_block;     // prefix over traversal blocks
+    uint32_t first_group;     // prefix over groups
+};
+
+__device__ __forceinline__ int find_task(const Task* __restrict__ tasks, int ntasks, uint32_t b, bool by_group) {
+    int lo = 0, hi = ntasks - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const uint32_t first = by_group ? tasks[mid].first_group : tasks[mid].first_block;
+        if (first <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Upstream-gradient pointers change every step (autograd allocates them): they travel in the kernel
+// arguments (captured at launch, no staging buffer to race on), at most kBatchMax per launch.
+constexpr int kBatchMax = 256;
+struct PtrPack {
+    const float* dy[kBatchMax];
+};
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restrict__ tasks, int ntasks, uint32_t* ws, PtrPack pk,
+                                                           int use_pack) {
+    const int ti = find_task(tasks, ntasks, blockIdx.x, false);
+    const Task& t = tasks[ti];
+    Params p = t.p;
+    if (use_pack) p.dy = pk.dy[ti];
+    p.pa = ws + t.ws_off;
+    p.pb = p.pa + t.np_pad;
+    p.pc = reinterpret_cast<float*>(p.pb + t.np_pad);
+    const uint32_t b = blockIdx.x - t.first_block;
+    if (t.mode == 0) {
+        const uint32_t nc = (uint32_t)t.nc;
+        const uint32_t row = b / nc, ck = b - row * nc;
+        const int64_t g = (int64_t)(row % (uint32_t)p.G);
+        if (t.vec) row_stream_body<OP, 4, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
+        else row_stream_body<OP, 1, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
+    } else if (t.mode == 1) {
+        row_small_body<OP>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
+    } else {
+        const uint32_t nbx = (uint32_t)t.nbx;
+        const uint32_t y = b / nbx, bx = b - y * nbx;
+        col_body<OP>(p, t.C, t.rps, (int64_t)bx, (int64_t)y);
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(64) void k_batch_finalize(const Task* __restrict__ tasks, int ntasks, uint32_t* ws) {
+    const int ti = find_task(tasks, ntasks, blockIdx.x, true);
+    const Task& t = tasks[ti];
+    Params p = t.p;
+    p.pa = ws + t.ws_off;
+    p.pb = p.pa + t.np_pad;
+    p.pc = reinterpret_cast<float*>(p.pb + t.np_pad);
+    FinGeom f;
+    f.groups = p.G;
+    f.gstride = t.gstride;
+    f.n1 = t.n1;
+    f.stride1 = t.stride1;
+    f.n2 = t.n2;
+    f.count = t.count;
+    f.o0 = t.ds;
+    f.o1 = nullptr;
+    f.o2 = nullptr;
+    finalize_block_body<OP, 64>(p, f, (int64_t)(blockIdx.x - t.first_group));
+}
+
+// K6 for every scale of the batch in one launch: block per tensor.
+struct AdamTask {
+    float* s;
+    const float* ds;
+    float* m;
+    float* v;
+    int64_t n;
+    float min_value;
+    int pad;
+};
+
+__global__ __launch_bounds__(kBlock) void k_batch_adam(const AdamTask* __restrict__ tasks, float lr, float b1, float b2, double lr_d,
+                                                       double b1_d, double b2_d, float f0, float f1, float eps,
+                                                       const int64_t* step_dev, int64_t step_host, int mode) {
+    const AdamTask t = tasks[blockIdx.x];
+    const int64_t step = step_dev ? step_dev[0] : step_host;
+    float alpha = 0.f, step_size = 0.f, sq_bc2 = 1.f;
+    if (mode == LQ_ADAM_KERAS) {
+        const float b1p = powf(b1, (float)step), b2p = powf(b2, (float)step);
+        alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    } else {
+        const double bc1 = 1.0 - pow(b1_d, (double)step), bc2 = 1.0 - pow(b2_d, (double)step);
+        step_size = (float)(lr_d / bc1);
+        sq_bc2 = (float)sqrt(bc2);
+    }
+    for (int64_t i = threadIdx.x; i < t.n; i += kBlock) {
+        const float g = t.ds[i];
+        float mi = t.m[i], vi = t.v[i], w = t.s[i];
+        mi = mi + (g - mi) * f0;
+        vi = vi + (g * g - vi) * f1;
+        if (mode == LQ_ADAM_KERAS) w = w - (mi * alpha) / (sqrtf(vi) + eps);
+        else w = w - step_size * (mi / (sqrtf(vi) / sq_bc2 + eps));
+        w = (w < t.min_value) ? t.min_value : w;
+        t.m[i] = mi;
+        t.v[i] = vi;
+        t.s[i] = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 //  Host side: plan, launchers, C ABI.
 // ------------------------------------------------------------------------------------------
 enum Mode { MODE_ROW_BIG = 0, MODE_ROW_SMALL = 1, MODE_COL = 2 };
@@ -1028,7 +1174,7 @@ struct Plan {
 
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-static Plan make_plan(int64_t outer, int64_t G, int64_t inner) {
+static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0) {
     Plan pl;
     memset(&pl, 0, sizeof(pl));
     const int64_t N = outer * G * inner;
@@ -1075,8 +1221,11 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner) {
             pl.mode = MODE_ROW_BIG;
             // 512 threads: measured best on MI355X (BENCH bwd 44.9 us vs 53.6 us at 1024 -- fewer waves held at the
             // closing barrier -- and vs 48.4 us at 256; the forward is insensitive)
-            pl.bs = L >= 2048 ? 512 : 256;
-            if (const char* e = getenv("LQ_TUNE_BS")) {   // development knob (tools/): force the streaming block size
+            // Below 4 M elements a tensor is latency-bound and keeps 256-thread units, the geometry the
+            // multi-tensor batch kernels use -- so batched and single-tensor results are bit-identical there.
+            pl.bs = (L >= 2048 && (double)R * (double)L >= 4194304.0) ? 512 : 256;
+            if (force_bs) pl.bs = force_bs;
+            else if (const char* e = getenv("LQ_TUNE_BS")) {   // development knob (tools/): force the streaming block size
                 const int v = atoi(e);
                 if ((v == 256 || v == 512 || v == 1024) && L >= v * 4) pl.bs = v;
             }
@@ -1491,6 +1640,203 @@ int lq_q_absmax_over_axis(const float* P, const float* s, float* result, int64_t
     LQ_REQUIRE_PTR(result);
     hipLaunchKernelGGL(k_q_absmax_axis, dim3((unsigned)ceil_div(pre * post, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, P, s, result, pre, n_axis, post, G, inner);
     return check_hip("absmax axis launch");
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+//  lq_batch: host object + C ABI
+// ------------------------------------------------------------------------------------------
+struct lq_batch {
+    int n = 0;
+    std::vector<lq::Task> fwd_h, bwd_h;
+    std::vector<int> bwd_index;          // bwd task -> descriptor index
+    std::vector<lq::AdamTask> adam_h;
+    lq::Task* fwd_d = nullptr;
+    lq::Task* bwd_d = nullptr;
+    lq::AdamTask* adam_d = nullptr;
+    uint32_t fwd_blocks = 0, bwd_blocks = 0, bwd_groups = 0;
+    size_t ws_bytes = 256;
+};
+
+namespace lq {
+
+static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, uint32_t& block_prefix, uint32_t& group_prefix, int64_t& ws_words) {
+    memset(&t, 0, sizeof(t));
+    const Plan pl = make_plan(d.outer, d.G, d.inner, kBlock);
+    t.p = base_params(d.P, d.s, d.outer, d.G, d.inner);
+    t.p.out = d.out;
+    t.p.dy = d.dy;
+    t.p.lam = d.lambda;
+    t.p.tmode = (d.lambda < 4.0e-4f) ? 0 : ((d.lambda <= 0.25f) ? 1 : 2);
+    t.ds = d.ds;
+    t.mode = pl.mode;
+    t.lpr_log2 = pl.lpr_log2;
+    t.R = pl.R;
+    t.L = pl.L;
+    t.nc = pl.nc;
+    t.C = pl.C;
+    t.rps = pl.rps;
+    t.nbx = pl.mode == MODE_COL ? ceil_div(pl.C, kBlock) : 0;
+    int64_t blocks;
+    if (pl.mode == MODE_ROW_BIG) {
+        blocks = pl.R * pl.nc;
+        // float4 path: forward needs P and out 16-byte aligned; backward needs P (dy is checked at every launch)
+        t.vec = ((pl.L % 4 == 0 || pl.R == 1) && aligned(d.P, 16) && (bwd || aligned(d.out, 16))) ? 1 : 0;
+    } else if (pl.mode == MODE_ROW_SMALL) {
+        blocks = ceil_div(pl.R, kBlock >> pl.lpr_log2);
+    } else {
+        blocks = t.nbx * pl.ysplit;
+    }
+    if (blocks <= 0 || blocks > 0x7fffffffll || (uint64_t)block_prefix + (uint64_t)blocks > 0xffffffffull)
+        return fail(LQ_EINVAL, "lq_batch_create: too many blocks");
+    t.first_block = block_prefix;
+    block_prefix += (uint32_t)blocks;
+    t.first_group = group_prefix;
+    if (bwd) {
+        if ((uint64_t)group_prefix + (uint64_t)d.G > 0xffffffffull) return fail(LQ_EINVAL, "lq_batch_create: too many groups");
+        group_prefix += (uint32_t)d.G;
+        t.np_pad = (pl.np + 63) / 64 * 64;
+        t.ws_off = ws_words;
+        ws_words += 3 * t.np_pad;
+        t.gstride = pl.gstride;
+        t.n1 = pl.n1;
+        t.stride1 = pl.stride1;
+        t.n2 = pl.n2;
+        t.count = (double)d.outer * (double)d.inner;
+    }
+    return LQ_OK;
+}
+
+}  // namespace lq
+
+extern "C" {
+
+int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
+    if (!descs || !out) return fail(LQ_EINVAL, "lq_batch_create: NULL argument");
+    if (n <= 0 || n > kBatchMax) return fail(LQ_EINVAL, "lq_batch_create: n must be in 1..%d", kBatchMax);
+    lq_batch* b = new (std::nothrow) lq_batch();
+    if (!b) return fail(LQ_EHIP, "lq_batch_create: out of host memory");
+    b->n = n;
+    int64_t ws_words = 0, dummy = 0;
+    uint32_t gp_dummy = 0;
+    for (int i = 0; i < n; ++i) {
+        const lq_tensor_desc& d = descs[i];
+        int rc = check_desc(d.outer, d.G, d.inner);
+        if (!rc && (!d.P || !d.s || !d.out)) rc = fail(LQ_EINVAL, "lq_batch_create: tensor %d has a NULL P/s/out", i);
+        if (!rc && (!aligned(d.P, 4) || !aligned(d.s, 4) || !aligned(d.out, 4))) rc = fail(LQ_EALIGN, "lq_batch_create: tensor %d misaligned", i);
+        Task t;
+        if (!rc) rc = fill_task(t, d, false, b->fwd_blocks, gp_dummy, dummy);
+        if (rc) {
+            delete b;
+            return rc;
+        }
+        b->fwd_h.push_back(t);
+        if (d.lambda == d.lambda) {   // not NaN: nested-quantization tensor with a scale gradient
+            if (!d.ds) {
+                delete b;
+                return fail(LQ_EINVAL, "lq_batch_create: tensor %d has lambda but no ds", i);
+            }
+            Task tb;
+            rc = fill_task(tb, d, true, b->bwd_blocks, b->bwd_groups, ws_words);
+            if (rc) {
+                delete b;
+                return rc;
+            }
+            b->bwd_h.push_back(tb);
+            b->bwd_index.push_back(i);
+        }
+        if (d.m && d.v) {
+            AdamTask a;
+            memset(&a, 0, sizeof(a));
+            a.s = const_cast<float*>(d.s);
+            a.ds = d.ds;
+            a.m = d.m;
+            a.v = d.v;
+            a.n = d.G;
+            a.min_value = d.min_value;
+            if (!d.ds) {
+                delete b;
+                return fail(LQ_EINVAL, "lq_batch_create: tensor %d has Adam state but no ds", i);
+            }
+            b->adam_h.push_back(a);
+        }
+    }
+    b->ws_bytes = (size_t)ws_words * 4 + 256;
+    hipError_t e = hipMalloc(&b->fwd_d, b->fwd_h.size() * sizeof(Task));
+    if (e == hipSuccess) e = hipMemcpy(b->fwd_d, b->fwd_h.data(), b->fwd_h.size() * sizeof(Task), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !b->bwd_h.empty()) {
+        e = hipMalloc(&b->bwd_d, b->bwd_h.size() * sizeof(Task));
+        if (e == hipSuccess) e = hipMemcpy(b->bwd_d, b->bwd_h.data(), b->bwd_h.size() * sizeof(Task), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !b->adam_h.empty()) {
+        e = hipMalloc(&b->adam_d, b->adam_h.size() * sizeof(AdamTask));
+        if (e == hipSuccess) e = hipMemcpy(b->adam_d, b->adam_h.data(), b->adam_h.size() * sizeof(AdamTask), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        const int rc = fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
+        lq_batch_destroy(b);
+        return rc;
+    }
+    *out = b;
+    return LQ_OK;
+}
+
+int lq_batch_destroy(lq_batch* b) {
+    if (!b) return LQ_OK;
+    if (b->fwd_d) (void)hipFree(b->fwd_d);
+    if (b->bwd_d) (void)hipFree(b->bwd_d);
+    if (b->adam_d) (void)hipFree(b->adam_d);
+    delete b;
+    return LQ_OK;
+}
+
+size_t lq_batch_workspace_bytes(const lq_batch* b) { return b ? b->ws_bytes : 0; }
+
+int lq_batch_forward(const lq_batch* b, void* stream) {
+    if (!b) return fail(LQ_EINVAL, "lq_batch_forward: NULL batch");
+    PtrPack pk;
+    hipLaunchKernelGGL((k_batch_traverse<OP_FWD>), dim3(b->fwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->fwd_d,
+                       (int)b->fwd_h.size(), (uint32_t*)nullptr, pk, 0);
+    return check_hip("batch forward launch");
+}
+
+int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream) {
+    if (!b) return fail(LQ_EINVAL, "lq_batch_scale_grad: NULL batch");
+    if (b->bwd_h.empty()) return LQ_OK;
+    if (!ws) return fail(LQ_EWORKSPACE, "lq_batch_scale_grad: workspace is NULL (need %zu bytes)", b->ws_bytes);
+    if (!aligned(ws, 16)) return fail(LQ_EALIGN, "lq_batch_scale_grad: workspace must be 16-byte aligned");
+    if (ws_bytes < b->ws_bytes) return fail(LQ_EWORKSPACE, "lq_batch_scale_grad: workspace too small: %zu < %zu bytes", ws_bytes, b->ws_bytes);
+    PtrPack pk;
+    memset(&pk, 0, sizeof(pk));
+    bool all_aligned = true;
+    for (size_t i = 0; i < b->bwd_h.size(); ++i) {
+        const float* d = dy ? dy[b->bwd_index[i]] : b->bwd_h[i].p.dy;
+        if (!d) return fail(LQ_EINVAL, "lq_batch_scale_grad: no upstream gradient for tensor %d", b->bwd_index[i]);
+        if (!aligned(d, 4)) return fail(LQ_EALIGN, "lq_batch_scale_grad: dy of tensor %d misaligned", b->bwd_index[i]);
+        if (b->bwd_h[i].mode == MODE_ROW_BIG && b->bwd_h[i].vec && !aligned(d, 16)) all_aligned = false;
+        pk.dy[i] = d;
+    }
+    if (!all_aligned) return fail(LQ_EALIGN, "lq_batch_scale_grad: a 16-byte aligned tensor got a dy that is not 16-byte aligned");
+    hipLaunchKernelGGL((k_batch_traverse<OP_BWD>), dim3(b->bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->bwd_d,
+                       (int)b->bwd_h.size(), (uint32_t*)ws, pk, 1);
+    int rc = check_hip("batch scale-grad launch");
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_batch_finalize<OP_BWD>), dim3(b->bwd_groups), dim3(64), 0, (hipStream_t)stream, b->bwd_d,
+                       (int)b->bwd_h.size(), (uint32_t*)ws);
+    return check_hip("batch finalize launch");
+}
+
+int lq_batch_scale_adam(const lq_batch* b, double lr, double beta1, double beta2, double eps, int64_t step,
+                        const int64_t* step_dev, int mode, void* stream) {
+    if (!b) return fail(LQ_EINVAL, "lq_batch_scale_adam: NULL batch");
+    if (b->adam_h.empty()) return LQ_OK;
+    if (!step_dev && step < 1) return fail(LQ_EINVAL, "lq_batch_scale_adam: step is 1-based");
+    if (mode != LQ_ADAM_KERAS && mode != LQ_ADAM_TORCH) return fail(LQ_EINVAL, "lq_batch_scale_adam: bad mode %d", mode);
+    hipLaunchKernelGGL(k_batch_adam, dim3((unsigned)b->adam_h.size()), dim3(kBlock), 0, (hipStream_t)stream, b->adam_d, (float)lr,
+                       (float)beta1, (float)beta2, lr, beta1, beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+                       step_dev, step, mode);
+    return check_hip("batch adam launch");
 }
 
 }  // extern "C"

@@ -229,8 +229,9 @@ class CustomDenseLayer(_HostLayer):
     def call(self, inputs):
         if not self.built:
             self.build(tuple(inputs.shape), device=inputs.device)
-        qw = self.nested_q_w_layer(self.W)                       # NQ-L:265
-        qb = self.nested_q_b_layer(self.b)                       # NQ-L:266
+        pre, self._q_pre = getattr(self, "_q_pre", None), None   # set by FakeQuantBatch.quantize_all() (one launch for all)
+        qw = pre[0] if pre is not None else self.nested_q_w_layer(self.W)     # NQ-L:265
+        qb = pre[1] if pre is not None else self.nested_q_b_layer(self.b)     # NQ-L:266
         return torch.add(torch.matmul(inputs, qw), qb)           # NQ-L:268
 
     forward = call
@@ -308,7 +309,8 @@ class _ConvBase(_HostLayer):
     def call(self, inputs):
         if not self.built:
             self.build(tuple(inputs.shape), device=inputs.device)
-        qk = self.nested_q_k_layer(self.kernel)                                            # NQ-L:340
+        pre, self._q_pre = getattr(self, "_q_pre", None), None   # set by FakeQuantBatch.quantize_all() (one launch for all)
+        qk = pre[0] if pre is not None else self.nested_q_k_layer(self.kernel)             # NQ-L:340
         x = inputs.permute(0, 3, 1, 2) if self.data_format == "NHWC" else inputs
         w = qk.permute(3, 2, 0, 1)                                                         # HWIO -> OIHW view
         if self.padding == "SAME":
@@ -321,7 +323,7 @@ class _ConvBase(_HostLayer):
         else:
             y = F.conv2d(x, w, None, self.strides, 0)                                      # NQ-L:343-348
         if self._has_bias:
-            qb = self.nested_q_b_layer(self.b)                                             # NQ-L:341
+            qb = pre[1] if pre is not None else self.nested_q_b_layer(self.b)              # NQ-L:341
             y = torch.add(y, qb.view(1, -1, 1, 1))                                         # NQ-L:350
         return y.permute(0, 2, 3, 1) if self.data_format == "NHWC" else y
 

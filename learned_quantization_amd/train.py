@@ -45,7 +45,7 @@ def synthetic_batch(config: str, batch: int, device, generator: Optional[torch.G
 
 class Trainer:
     def __init__(self, config="cifar", mode="nq", value=1e-11, orientation="channelwise", loss: Optional[str] = None,
-                 lr=1e-4, seed=42, device=None, ddp_mode="A", log_dir="logs", graph=False):
+                 lr=1e-4, seed=42, device=None, ddp_mode="A", log_dir="logs", graph=False, batched=False):
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         torch.manual_seed(seed)
         L.reset_layer_names()
@@ -63,7 +63,16 @@ class Trainer:
         if graph and self.world > 1:
             raise ValueError("graph capture of the whole step is single-GPU only (the all-reduce stays eager)")
         self.opt = torch.optim.Adam(non_scale_parameters(self.model), lr=lr, eps=1e-7, capturable=graph)   # Keras Adam defaults
-        self.scale_opt = ScaleAdam(scale_parameters(self.model), lr=lr, capturable=graph)
+        self.batch = None
+        if batched:
+            # one launch for every fake-quant forward, two for every scale gradient, one for every scale update
+            from .batch import BatchedScaleAdam, FakeQuantBatch
+            if self.dp is not None:
+                self.dp.zero_grad()          # makes scale.grad the bucket views the batch will write into
+            self.batch = FakeQuantBatch(self.model, lr=lr)
+            self.scale_opt = BatchedScaleAdam(self.batch, capturable=graph)
+        else:
+            self.scale_opt = ScaleAdam(scale_parameters(self.model), lr=lr, capturable=graph)
         self.regularized = [l for l in self.custom_layers if l.regularizer is not None]
         self.graph = None
         self._want_graph = graph
@@ -85,6 +94,8 @@ class Trainer:
         else:
             self.opt.zero_grad(set_to_none=True)
             self.scale_opt.zero_grad(set_to_none=True)
+        if self.batch is not None:
+            self.batch.quantize_all()
         loss = self.loss(y, self.model(x))
         loss.backward()
         if self.dp is not None:
@@ -140,6 +151,7 @@ def main(argv=None):
     ap.add_argument("--ddp-mode", choices=["A", "B"], default="A")
     ap.add_argument("--export-dir", default=None, help="write the reference's integer export here at the end")
     ap.add_argument("--graph", action="store_true", help="capture the whole step in a hipGraph (single GPU)")
+    ap.add_argument("--batched", action="store_true", help="multi-tensor launches for all fake-quant ops of a step (lq_batch_*)")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,7 +166,7 @@ def main(argv=None):
     rank = dist.get_rank() if world > 1 else 0
 
     tr = Trainer(args.config, args.mode, args.value, args.orientation, args.loss, seed=args.seed, device=dev,
-                 ddp_mode=args.ddp_mode, graph=args.graph)
+                 ddp_mode=args.ddp_mode, graph=args.graph, batched=args.batched)
     do_step = tr.step_graphed if args.graph else tr.step
     g = torch.Generator(device=dev).manual_seed(args.seed + rank)
     batches = [synthetic_batch(args.config, args.batch, dev, g) for _ in range(4)]
@@ -181,7 +193,7 @@ def main(argv=None):
             "value": world * args.batch * args.steps / dt, "unit": "images/s", "n_gpus": world,
             "ms_per_step": dt / args.steps * 1e3, "per_gpu_batch": args.batch, "orientation": args.orientation,
             "loss_term": args.loss, "quantized_elements": n_q, "final_loss": float(loss), "ddp_mode": args.ddp_mode,
-            "hipgraph": bool(args.graph)}))
+            "hipgraph": bool(args.graph), "batched": bool(args.batched)}))
         if args.export_dir:
             from .export import save_compress_parameters
             print(json.dumps(save_compress_parameters(tr.model, args.export_dir)))

@@ -232,3 +232,20 @@ def test_bench_shape_full_size_properties(dev):
     _, p1 = lq.fq_scale_grad(x, s, dy, 1e-3, return_parts=True)
     _, p2 = lq.fq_scale_grad(x, s, dy * 4.0, 4e-3, return_parts=True)
     assert torch.equal(p1[2], p2[2]) and torch.equal(p1[0], p2[0])
+
+
+def test_c_abi_without_python(dev, tmp_path):
+    """Builds tests/tools/abi_smoke.cpp with hipcc and runs it: the boundary is usable from plain C/C++."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(root, "learned_quantization_amd", "csrc")
+    subprocess.check_call([hipcc, "-O2", "--offload-arch=gfx950", "-I", os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "tests", "tools", "abi_smoke.cpp"), "-L", libdir, "-llq_hip",
+                           f"-Wl,-rpath,{libdir}"])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "0 mismatches" in res.stdout

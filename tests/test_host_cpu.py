@@ -170,3 +170,25 @@ def test_sparse_categorical_crossentropy_matches_oracle():
     got = lq.sparse_categorical_crossentropy(torch.tensor(y), torch.tensor(p)).numpy()
     np.testing.assert_allclose(got, O.sparse_categorical_crossentropy(y, p), rtol=1e-6)
     assert got[0] == pytest.approx(-np.log(1e-7), rel=1e-5)
+
+
+def test_missing_extension_fails_loudly():
+    """No silent fallback: if liblq_hip.so is absent every op raises (checked in a fresh interpreter)."""
+    import subprocess
+    import sys
+    code = ("import os, sys; os.environ['LQ_HIP_LIB'] = '/nonexistent/liblq_hip.so'; sys.path.insert(0, %r);\n"
+            "import torch, learned_quantization_amd as lq\n"
+            "try:\n    lq.fq_forward(torch.ones(4), torch.ones(1))\nexcept RuntimeError as e:\n    print('RAISED', e)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "RAISED" in out.stdout and "HIP extension not built" in out.stdout, out.stdout + out.stderr
+
+
+def test_fast_division_sequence_is_exact_on_cpu(tmp_path):
+    """tests/tools/check_fast_div.c: the uniform-divisor division of the kernels == IEEE '/' for all 2^23
+    mantissas x 3 exponents x both signs, per divisor (16 fixed + 8 random divisors here; 1516 were run once)."""
+    import subprocess
+    exe = str(tmp_path / "check_fast_div")
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "tools", "check_fast_div.c"), "-lm"])
+    res = subprocess.run([exe, "8", "2024"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and " 0 mismatches" in res.stdout, res.stdout + res.stderr
