@@ -60,10 +60,13 @@ def test_batch_equals_single_tensor_ops_bitwise(dev, config, orient):
 
 def test_batched_training_matches_unbatched(dev, tmp_path):
     from learned_quantization_amd.train import Trainer, synthetic_batch
-    x, y = synthetic_batch("cifar", 32, dev, torch.Generator(device=dev).manual_seed(0))
+    # the dense model: rocBLAS GEMMs are run-to-run deterministic, MIOpen's convolution weight-gradients are not, and the
+    # thresholded scale gradient amplifies last-bit differences of dy (a group flipping "all above" changes ds by orders
+    # of magnitude) -- the bitwise equality of every fake-quant result is covered by the previous test
+    x, y = synthetic_batch("mnist", 32, dev, torch.Generator(device=dev).manual_seed(0))
     results = []
     for batched in (False, True):
-        tr = Trainer("cifar", "nq", 1e-3, "channelwise", None, device=dev, log_dir=str(tmp_path), batched=batched)
+        tr = Trainer("mnist", "nq", 1e-3, "rowwise", None, device=dev, log_dir=str(tmp_path), batched=batched)
         tr.model.eval()             # no dropout randomness / BN batch statistics in the comparison
         losses = []
         for _ in range(3):
@@ -77,11 +80,9 @@ def test_batched_training_matches_unbatched(dev, tmp_path):
             tr.scale_opt.step()
             losses.append(float(loss))
         results.append((losses, [s.detach().clone() for s in tr.scale_opt.param_groups[0]["params"]]))
-    # the two runs share every fake-quant result bit for bit (previous test); MIOpen's weight-gradient kernels are not
-    # run-to-run deterministic, and the thresholded scale gradient amplifies last-bit differences of dy slightly
-    np.testing.assert_allclose(results[0][0], results[1][0], rtol=1e-4)
+    np.testing.assert_allclose(results[0][0], results[1][0], rtol=1e-5)
     for a, b in zip(results[0][1], results[1][1]):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-3)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5)
 
 
 def test_batch_ste_only_tensors_and_errors(dev):

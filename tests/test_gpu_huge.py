@@ -1,0 +1,84 @@
+"""Maximum-size test: > 2^31 elements (8.6 GB per tensor) with a ragged tail -- 64-bit index arithmetic in the
+streaming kernels, block counts beyond 2^20, partial counts beyond 10^6.  The element-wise reference is torch on
+the same device in chunks (IEEE division, floor, multiply: the same three fp32 ops as the oracle, which is checked
+on slices at the start, across the 2^31 boundary and at the end); reductions are accumulated in float64."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lq_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_more_than_2_to_31_elements():
+    import learned_quantization_amd as lq
+    dev = torch.device("cuda:0")
+    if torch.cuda.get_device_properties(0).total_memory < 60 * 2 ** 30:
+        pytest.skip("needs ~40 GB of device memory")
+    n = 2 ** 31 + 4096 + 3
+    g = torch.Generator(device=dev).manual_seed(1)
+    P = torch.empty(n, device=dev)
+    dy = torch.empty(n, device=dev)
+    step = 1 << 28
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        P[a:b] = torch.rand(b - a, device=dev, generator=g) * 200.0 - 100.0
+        dy[a:b] = torch.randn(b - a, device=dev, generator=g) * 1e-3
+    s = torch.tensor([0.37], device=dev)
+    lam = 2e-5
+    out, q = lq.fq_forward(P, s, q_dtype=torch.int32)
+    # oracle on slices (start, across 2^31, ragged end)
+    for a, b in ((0, 5000), (2 ** 31 - 3000, 2 ** 31 + 3000), (n - 5000, n)):
+        q_o, out_o = O.fq_forward(P[a:b].cpu().numpy(), s.cpu().numpy())
+        np.testing.assert_array_equal(out[a:b].cpu().numpy(), out_o)
+        np.testing.assert_array_equal(q[a:b].cpu().numpy(), q_o.astype(np.int32))
+    # whole tensor against the same three fp32 ops in torch, chunked
+    maxq, below, total = 0.0, 0, 0.0
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        qr = torch.floor(P[a:b] / s)
+        outr = qr * s
+        assert torch.equal(out[a:b], outr), f"chunk {a}"
+        assert torch.equal(q[a:b], qr.to(torch.int32))
+        maxq = max(maxq, float(qr.abs().max()))
+        nz = torch.where(outr == 0, torch.full_like(outr, O.EPS_F32), outr)
+        ratio = dy[a:b].abs() / nz.abs()
+        m = ~(ratio >= lam)
+        below += int(m.sum())
+        total += float((-torch.tanh(lam - ratio[m]).abs()).double().sum())
+        del qr, outr, nz, ratio, m
+    ds, parts = lq.fq_scale_grad(P, s, dy, lam, return_parts=True)
+    parts = parts.cpu().numpy()
+    assert parts[0, 0] == maxq
+    assert int(parts[2, 0]) == below or abs(parts[2, 0] - below) <= 128      # float32 readout of an exact count
+    mean = total / n
+    np.testing.assert_allclose(parts[1, 0], mean, rtol=1e-5)
+    np.testing.assert_allclose(float(ds), mean * maxq, rtol=1e-5)
+    out2, ds2 = lq.fq_fwd_bwd_fused(P, s, dy, lam, out=out)
+    assert torch.equal(ds2, ds)
+    for a, b in ((2 ** 31 - 3000, 2 ** 31 + 3000), (n - 5000, n)):
+        _, out_o = O.fq_forward(P[a:b].cpu().numpy(), s.cpu().numpy())
+        np.testing.assert_array_equal(out2[a:b].cpu().numpy(), out_o)
+
+
+def test_rows_longer_than_2_to_30_with_per_row_scales():
+    import learned_quantization_amd as lq
+    dev = torch.device("cuda:0")
+    if torch.cuda.get_device_properties(0).total_memory < 60 * 2 ** 30:
+        pytest.skip("needs ~30 GB of device memory")
+    L = 2 ** 30 + 2048 + 4
+    P = torch.empty(2, L, device=dev)
+    g = torch.Generator(device=dev).manual_seed(2)
+    for r in range(2):
+        for a in range(0, L, 1 << 28):
+            b = min(L, a + (1 << 28))
+            P[r, a:b] = torch.randn(b - a, device=dev, generator=g) * 0.05
+    s = torch.tensor([[0.011], [0.0037]], device=dev)
+    out = lq.fq_forward(P, s)
+    for r in range(2):
+        for a in range(0, L, 1 << 28):
+            b = min(L, a + (1 << 28))
+            assert torch.equal(out[r, a:b], torch.floor(P[r, a:b] / s[r]) * s[r])
+    _, out_o = O.fq_forward(P[:, L - 3000:].cpu().numpy(), s.cpu().numpy())
+    np.testing.assert_array_equal(out[:, L - 3000:].cpu().numpy(), out_o)
