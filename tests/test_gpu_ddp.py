@@ -1,0 +1,68 @@
+"""Two-process data-parallel training on ONE MI355X (both ranks use cuda:0, gloo transport): the DataParallel bucket,
+modes A/B and the batched path run with the real HIP kernels.  (RCCL needs one GPU per rank; the 8-GPU run is the
+driver's.)  Mode B must reproduce the single-process global-batch result; mode A the mean of the local scale grads."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _data(dev):
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(16, 1, 28, 28, generator=g) * 255.0).to(dev)
+    y = torch.randint(0, 10, (16,), generator=g).to(dev)
+    return x, y
+
+
+def _worker(rank, world, port, mode, batched, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    from learned_quantization_amd.train import Trainer
+    tr = Trainer("mnist", "nq", 2e-4, "rowwise", None, device=dev, ddp_mode=mode, batched=batched, seed=42 + 7 * rank)
+    x, y = _data(dev)
+    xs, ys = x[rank * 8:(rank + 1) * 8], y[rank * 8:(rank + 1) * 8]
+    losses = [float(tr.step(xs, ys).detach()) for _ in range(2)]
+    res = {n: p.detach().cpu().clone() for n, p in tr.model.named_parameters()}
+    res["losses"] = losses
+    torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,batched", [("A", False), ("B", False), ("A", True)])
+def test_two_rank_training_on_one_gpu(tmp_path, mode, batched):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, mode, batched, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    for k in r0:
+        if k != "losses":
+            assert torch.equal(r0[k], r1[k]), f"replicas diverged at {k} (mode {mode})"   # same init (broadcast) + same update
+    if mode == "B":
+        # exact mode == single process on the global batch
+        sys.path.insert(0, ROOT)
+        from learned_quantization_amd.train import Trainer
+        dev = torch.device("cuda:0")
+        tr = Trainer("mnist", "nq", 2e-4, "rowwise", None, device=dev, seed=42)       # rank 0's seed: the broadcast source
+        x, y = _data(dev)
+        for _ in range(2):
+            tr.step(x, y)
+        for n, p in tr.model.named_parameters():
+            np.testing.assert_allclose(r0[n].numpy(), p.detach().cpu().numpy(), rtol=2e-5, atol=1e-9, err_msg=n)
