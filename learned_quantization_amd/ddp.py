@@ -16,6 +16,10 @@ custom_layers.py:97-111), so two modes exist:
       communicated: bit-identical on all ranks and equal to the single-device large-batch result.
       Weight regularisers must stay out of P.grad until then (apply them in the optimizer).
 
+The exchange is bucketed (25 MiB sub-buckets, last layers first) and launched from gradient hooks so that it
+overlaps the remaining backward; xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce is bound
+by one link (44.7 MB -> ~0.5 ms), so overlapping it matters more than on a switched fabric.
+
 Works with any backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" for the CPU tests of the
 bucket logic.
 """
@@ -74,10 +78,16 @@ class DataParallel:
     """Wraps a module for data-parallel training.
 
     usage per step:  dp.zero_grad(); loss.backward(); dp.sync_gradients(); optimizer.step()
+
+    The flat bucket is cut into sub-buckets of ``bucket_mb`` MiB in reverse parameter order; a sub-bucket's
+    all-reduce is launched (asynchronously, RCCL's own stream) from a post-accumulate-grad hook as soon as every
+    parameter in it has its gradient, so the exchange of the late layers overlaps the backward of the early ones.
+    ``sync_gradients`` launches whatever is left and waits.  ``overlap=False`` = one all-reduce after backward.
     """
 
     def __init__(self, module: torch.nn.Module, mode: str = "A", group=None,
-                 scale_grad_fn: Optional[Callable] = None, broadcast: bool = True):
+                 scale_grad_fn: Optional[Callable] = None, broadcast: bool = True, bucket_mb: float = 25.0,
+                 overlap: bool = True):
         if mode not in ("A", "B"):
             raise ValueError("mode must be 'A' or 'B'")
         self.module = module
@@ -89,15 +99,68 @@ class DataParallel:
         self.others = [p for p in params if not getattr(p, "lq_is_scale", False)]
         # mode B never communicates ds: scales stay outside the bucket
         self.bucket = GradBucket(params if mode == "A" else self.others)
-        if broadcast and dist.is_initialized() and dist.get_world_size(group) > 1:
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if broadcast and dist.is_initialized() and self.world > 1:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        # ---- sub-buckets (contiguous ranges of the flat buffer), last parameters first
+        self._ranges: List[Tuple[int, int]] = []
+        self._param_bucket = {}
+        self._pending_count: List[int] = []
+        self._handles: List = []
+        self._launched: List[bool] = []
+        self.overlap = overlap and self.world > 1
+        limit = max(int(bucket_mb * (1 << 20) / 4), 1)
+        offsets = []
+        off = 0
+        for n in self.bucket.sizes:
+            offsets.append(off)
+            off += n
+        hi = off
+        cur_lo, cur_params = hi, []
+        for idx in range(len(self.bucket.params) - 1, -1, -1):
+            cur_lo = offsets[idx]
+            cur_params.append(idx)
+            if hi - cur_lo >= limit or idx == 0:
+                b = len(self._ranges)
+                self._ranges.append((cur_lo, hi))
+                for i in cur_params:
+                    self._param_bucket[i] = b
+                self._pending_count.append(len(cur_params))
+                hi, cur_params = cur_lo, []
+        self._remaining = list(self._pending_count)
+        self._launched = [False] * len(self._ranges)
+        if self.overlap:
+            for i, p in enumerate(self.bucket.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def __call__(self, *a, **k):
         return self.module(*a, **k)
 
+    def _make_hook(self, i):
+        def hook(_param):
+            b = self._param_bucket[i]
+            self._remaining[b] -= 1
+            if self._remaining[b] == 0 and not self._launched[b]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        lo, hi = self._ranges[b]
+        for i, p in enumerate(self.bucket.params):        # a grad re-allocated elsewhere goes back into the bucket first
+            if self._param_bucket[i] == b and p.grad is not None and p.grad.data_ptr() != self.bucket.views[i].data_ptr():
+                self.bucket.views[i].copy_(p.grad)
+                p.grad = self.bucket.views[i]
+        chunk = self.bucket.flat[lo:hi]
+        chunk.div_(self.world)
+        self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._launched[b] = True
+
     def zero_grad(self):
         self.bucket.zero_()
+        self._remaining = list(self._pending_count)
+        self._launched = [False] * len(self._ranges)
+        self._handles = []
         if self.mode == "B":
             for s in self.scales:
                 s.grad = None
@@ -114,8 +177,14 @@ class DataParallel:
         return pairs
 
     def sync_gradients(self):
-        self.bucket.gather_()
-        self.bucket.all_reduce_mean_(self.group)
+        if self.world > 1:
+            self.bucket.gather_()
+            for b in range(len(self._ranges)):
+                if not self._launched[b]:                  # parameters that got no gradient this step, or overlap=False
+                    self._launch(b)
+            for h in self._handles:
+                h.wait()
+            self._handles = []
         if self.mode == "B":
             fn = self._scale_grad_fn
             if fn is None:

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Weight-shaped sweeps: the per-step set of quantised tensors of the BASELINE configs
+C1 (MNIST 2-dense, 4 tensors, 101 770 el), C2 (CIFAR CNN, 12 tensors, 287 008 el), C3 (ResNet-18-like, 40 tensors,
+11 171 712 el) -- latency regime.  Reports microseconds per step (forward + scale gradient + scale update of the whole
+set) for the multi-tensor batch (lq_batch_*: 4 launches) and for the per-tensor entry points (4 launches per tensor),
+for all four orientations.  Weights ~ N(0, 0.05) seed 42, dy ~ N(0, 1e-3), scales at the reference's init value.
+
+    python tools/bench_weights.py [--steps 200] > profiles/r01_weight_sweeps.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import learned_quantization_amd as lq  # noqa: E402
+
+
+def timed(fn, steps, dev):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps * 1e6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=200)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    rows = []
+    for config, lam in (("mnist", 1e-10), ("cifar", 1e-11), ("imagenette", 1e-11)):
+        for orient in (("rowwise", "columnwise", "scalar") if config == "mnist" else ("rowwise", "columnwise", "channelwise", "scalar")):
+            lq.reset_layer_names()
+            model = lq.build_model(config, mode="nq", value=lam, seed=42, orientation=orient, device=dev)
+            batch = lq.FakeQuantBatch(model)
+            opt = lq.BatchedScaleAdam(batch)
+            g = torch.Generator(device=dev).manual_seed(42)
+            dys = [torch.randn(e.out.shape, device=dev, generator=g) * 1e-3 for e in batch.entries]
+            n_el = sum(e.param.numel() for e in batch.entries)
+
+            def batched_step():
+                outs = batch.quantize_all()
+                torch.autograd.backward(outs, dys)
+                opt.step()
+
+            single_opt = lq.ScaleAdam([e.nested.scale for e in batch.entries], lr=1e-4)
+
+            def per_tensor_step():
+                for e, d in zip(batch.entries, dys):
+                    lq.fq_forward(e.param.data, e.nested.scale.data)
+                    e.nested.scale.grad = lq.fq_scale_grad(e.param.data, e.nested.scale.data, d, lam)
+                single_opt.step()
+
+            # raw C-ABI cost without autograd/python per-tensor glue
+            lib = lq._hip.load()
+            sp = lq._hip.stream_ptr(dev)
+            import ctypes
+            ptrs = (ctypes.c_void_p * len(dys))(*[d.data_ptr() for d in dys])
+
+            def batched_abi_only():
+                lib.lq_batch_forward(batch._handle, sp)
+                lib.lq_batch_scale_grad(batch._handle, ptrs, batch.ws.data_ptr(), batch.ws.numel(), sp)
+                lib.lq_batch_scale_adam(batch._handle, 1e-4, 0.9, 0.999, 1e-7, 1, None, 0, sp)
+
+            rows.append({"config": config, "orientation": orient, "tensors": len(batch.entries), "elements": n_el,
+                         "us_per_step_batched_abi": timed(batched_abi_only, args.steps, dev),
+                         "us_per_step_batched_autograd": timed(batched_step, args.steps, dev),
+                         "us_per_step_per_tensor": timed(per_tensor_step, args.steps, dev)})
+            print(json.dumps(rows[-1]), flush=True)
+            del batch, model
+
+
+if __name__ == "__main__":
+    main()
