@@ -78,7 +78,7 @@ def _worker(rank, world, port, mode, out_dir):
             model.W.add_(1.0)
     # mode A with tiny sub-buckets: every parameter is its own overlapped all-reduce; mode B: one bucket
     dp = DataParallel(model, mode=mode, scale_grad_fn=_oracle_scale_grad, bucket_mb=(1e-5 if mode == "A" else 25.0))
-    assert len(dp._ranges) == (4 if mode == "A" else 1)
+    assert len(dp._ranges) == (3 if mode == "A" else 1)
     g = torch.Generator().manual_seed(123)
     X = torch.randn(8, 12, generator=g)
     Y = torch.randn(8, 5, generator=g)
