@@ -188,6 +188,13 @@ int lq_batch_scale_grad(const lq_batch* batch, const float* const* dy, void* ws,
 int lq_batch_scale_adam(const lq_batch* batch, double lr, double beta1, double beta2, double eps, int64_t step,
                         const int64_t* step_dev, int mode, void* stream);
 
+/* ---- device self-test -------------------------------------------------------------------
+ * Compares the kernels' in-window ratio division (rcp + Newton + fma chain, see lq_kernels.hip window_div)
+ * with the IEEE `/` on blocks*256*pairs_per_thread pseudo-random operand pairs in [2^-40, 2^40]; ADDS the
+ * number of bit mismatches to *mismatches_dev (uint64 on the device, zeroed by the caller). Expected: 0.   */
+int lq_selftest_ratio_division(uint64_t seed, uint32_t blocks, uint32_t pairs_per_thread, uint64_t* mismatches_dev,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -210,9 +210,32 @@ __device__ __forceinline__ void vote_ctx(Ctx& c, float lam) {
 }
 
 // exact vote of one element (IEEE ratio): custom_layers.py:64, :70/:97, :84/:110
+// ------------------------------------------------------------------------------------------
+//  a / b for per-element operands, bit-identical to the IEEE `/` inside a window.  hipcc expands `/` to
+//     d' = v_div_scale(b); n' = v_div_scale(a); r0 = v_rcp(d'); e = fma(-d',r0,1); r = fma(e,r0,r0);
+//     q0 = n'*r; e1 = fma(-d',q0,n'); q1 = fma(e1,r,q0); e2 = fma(-d',q1,n'); q = v_div_fmas(e2,r,q1); v_div_fixup
+//  For 2^-40 <= a,b <= 2^40 the two v_div_scale are identities (exponent difference < 96, no denormals),
+//  v_div_fmas is a plain fma and v_div_fixup changes nothing (no NaN/Inf/0 operands), so the SAME
+//  rcp + fma chain without them gives the same bits -- and, being plain fma/mul, is packed two-wide
+//  (v_pk_fma_f32) across the elements of a float4.  Verified on the device against `/` by
+//  lq_selftest_ratio_division (tests/test_gpu_parity.py) on 2^33 random in-window pairs.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float window_div(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r0, 1.0f);
+    const float r = __builtin_fmaf(e, r0, r0);
+    const float q0 = a * r;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(e1, r, q0);
+    const float e2 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(e2, r, q1);
+}
+constexpr float kWinLo = 9.094947017729282e-13f;   // 2^-40
+constexpr float kWinHi = 1.099511627776e+12f;      // 2^40
+
+// exact vote of one element given its IEEE ratio: custom_layers.py:70/:97, :84/:110
 template <int TM>
-__device__ __forceinline__ void vote_cast(float a, float b, float lam, Acc& acc) {
-    const float ratio = a / b;
+__device__ __forceinline__ void vote_tally(float ratio, float lam, Acc& acc) {
     const bool below = !(ratio >= lam);                  // NaN counts as "not above"
     acc.b += below ? 1u : 0u;
     const float t = abs_tanh_t<TM>(lam - ratio);
@@ -220,11 +243,33 @@ __device__ __forceinline__ void vote_cast(float a, float b, float lam, Acc& acc)
 }
 
 template <int TM>
+__device__ __forceinline__ void vote_cast(float a, float b, float lam, Acc& acc) {
+    vote_tally<TM>(a / b, lam, acc);                     // :64 (IEEE)
+}
+
+template <int TM>
 __device__ __forceinline__ void vote_cast4(const float4& dy, float b0, float b1, float b2, float b3, float lam, Acc& acc) {
-    vote_cast<TM>(fabsf(dy.x), b0, lam, acc);
-    vote_cast<TM>(fabsf(dy.y), b1, lam, acc);
-    vote_cast<TM>(fabsf(dy.z), b2, lam, acc);
-    vote_cast<TM>(fabsf(dy.w), b3, lam, acc);
+    const float a0 = fabsf(dy.x), a1 = fabsf(dy.y), a2 = fabsf(dy.z), a3 = fabsf(dy.w);
+    const float lo = fminf(fminf(fminf(a0, a1), fminf(a2, a3)), fminf(fminf(b0, b1), fminf(b2, b3)));
+    const float hi = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
+    // fminf/fmaxf skip a NaN operand: test every operand for NaN through one sum (NaN propagates through +)
+    const float nan_probe = (a0 + a1) + (a2 + a3) + ((b0 + b1) + (b2 + b3));
+    float r0, r1, r2, r3;
+    if ((lo >= kWinLo) & (hi <= kWinHi) & (nan_probe == nan_probe)) {
+        r0 = window_div(a0, b0);
+        r1 = window_div(a1, b1);
+        r2 = window_div(a2, b2);
+        r3 = window_div(a3, b3);
+    } else {
+        r0 = a0 / b0;
+        r1 = a1 / b1;
+        r2 = a2 / b2;
+        r3 = a3 / b3;
+    }
+    vote_tally<TM>(r0, lam, acc);
+    vote_tally<TM>(r1, lam, acc);
+    vote_tally<TM>(r2, lam, acc);
+    vote_tally<TM>(r3, lam, acc);
 }
 
 __device__ __forceinline__ void nq_accumulate4(const float4& q, const float4& o, const float4& dy, const Ctx& c, float lam,
@@ -591,10 +636,10 @@ __device__ __forceinline__ void store4(float* p, const float4& v) {
     }
 }
 
-template <int OP, int VEC, int BS, int NT>
+template <int OP, int VEC, int BS, int NT, int U = 1>
 __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int64_t nc, int64_t row, int64_t ck, int64_t g) {
     using O = OpT<OP>;
-    constexpr int CH = BS * 4;
+    constexpr int CH = BS * 4 * U;
     const int64_t base = row * L + ck * (int64_t)CH;
     const int64_t rem = L - ck * (int64_t)CH;
     const int len = rem < (int64_t)CH ? (int)rem : CH;
@@ -602,30 +647,42 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
 
     if (VEC == 4) {
         const int len4 = len >> 2;
-        const int j = (int)threadIdx.x;
         // Issue the streaming loads FIRST (they depend only on the kernel arguments and the block index);
         // the per-group context (scale fetch, reciprocal, thresholds) is computed while they are in flight.
         // Inactive lanes of a partial chunk re-read float4 0 of the chunk instead of branching.
         // A chunk with fewer than 4 elements (len4 == 0; only the last chunk of a flat row, so ck > 0)
         // reads the float4 just before it: always in bounds, never used.
-        const int64_t i = base + (int64_t)(j < len4 ? j : 0) * 4;
-        const int64_t il = len4 > 0 ? i : base - 4;
-        const float4 x = load4<NT>(p.P + il);
-        float4 d = x;
-        if (O::kDy) d = load4<NT>(p.dy + il);
+        // U = 2 (two float4 per thread and stream) is used when lambda >= 4e-4: every element then takes the
+        // exact-ratio + tanh branch, a wave's compute phase triples, and one float4 per thread no longer keeps
+        // enough bytes in flight per wave-lifetime to stay HBM-bound.
+        int64_t i[U];
+        float4 x[U], d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = u * BS + (int)threadIdx.x;
+            i[u] = base + (int64_t)(j < len4 ? j : 0) * 4;
+            const int64_t il = len4 > 0 ? i[u] : base - 4;
+            x[u] = load4<NT>(p.P + il);
+            d[u] = x[u];
+            if (O::kDy) d[u] = load4<NT>(p.dy + il);
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the scale fetch + reciprocal below
         const Ctx ctx = O::ctx(p, g);
-        if (j < len4) {
-            float4 r;
-            if constexpr (O::kVec4) {
-                r = O::elem4(p, ctx, i, x, d, acc);
-            } else {
-                r.x = O::elem(p, ctx, i + 0, x.x, O::kDy ? d.x : 0.f, acc);
-                r.y = O::elem(p, ctx, i + 1, x.y, O::kDy ? d.y : 0.f, acc);
-                r.z = O::elem(p, ctx, i + 2, x.z, O::kDy ? d.z : 0.f, acc);
-                r.w = O::elem(p, ctx, i + 3, x.w, O::kDy ? d.w : 0.f, acc);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = u * BS + (int)threadIdx.x;
+            if (j < len4) {
+                float4 r;
+                if constexpr (O::kVec4) {
+                    r = O::elem4(p, ctx, i[u], x[u], d[u], acc);
+                } else {
+                    r.x = O::elem(p, ctx, i[u] + 0, x[u].x, O::kDy ? d[u].x : 0.f, acc);
+                    r.y = O::elem(p, ctx, i[u] + 1, x[u].y, O::kDy ? d[u].y : 0.f, acc);
+                    r.z = O::elem(p, ctx, i[u] + 2, x[u].z, O::kDy ? d[u].z : 0.f, acc);
+                    r.w = O::elem(p, ctx, i[u] + 3, x[u].w, O::kDy ? d[u].w : 0.f, acc);
+                }
+                if (O::kStore) store4<NT>(p.out + i[u], r);
             }
-            if (O::kStore) store4<NT>(p.out + i, r);
         }
         // ragged scalar tail: only a single flat row (G == 1) can have len % 4 != 0 on the vector path
         const int tail = len & 3;
@@ -635,9 +692,9 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
             if (O::kStore) p.out[i] = r;
         }
     } else {
-        float x[4], d[4];
+        float x[4 * U], d[4 * U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 4 * U; ++u) {
             const int j = u * BS + (int)threadIdx.x;
             const int jc = j < len ? j : len - 1;      // clamp instead of predicate: the loads stay in flight together
             x[u] = p.P[base + jc];
@@ -645,7 +702,7 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
         }
         const Ctx ctx = O::ctx(p, g);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 4 * U; ++u) {
             const int j = u * BS + (int)threadIdx.x;
             if (j < len) {
                 float r = O::elem(p, ctx, base + j, x[u], d[u], acc);
@@ -663,7 +720,7 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
     }
 }
 
-template <int OP, int VEC, int BS, int NT>
+template <int OP, int VEC, int BS, int NT, int U = 1>
 __global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params p, int64_t L, int64_t nc, int grid3d) {
     int64_t row, ck, g;
     if (grid3d) {
@@ -676,7 +733,7 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params 
         ck = unit - row * nc;
         g = row % p.G;
     }
-    row_stream_body<OP, VEC, BS, NT>(p, L, nc, row, ck, g);
+    row_stream_body<OP, VEC, BS, NT, U>(p, L, nc, row, ck, g);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1030,6 +1087,29 @@ __global__ void k_q_absmax_axis(const float* P, const float* s, float* result, i
 }
 
 // ------------------------------------------------------------------------------------------
+//  Device self-test of window_div against the IEEE division (random in-window operand pairs).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_selftest_ratio_div(uint64_t seed, uint32_t per_thread, unsigned long long* mismatches) {
+    uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * ((uint64_t)blockIdx.x * kBlock + threadIdx.x + 1));
+    unsigned long long bad = 0;
+    for (uint32_t k = 0; k < per_thread; ++k) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        // exponents 87..167 (2^-40 .. 2^40), random mantissas; the top of the window is clamped to exactly 2^40
+        uint32_t ea = 87u + (uint32_t)((x >> 8) % 81u), eb = 87u + (uint32_t)((x >> 24) % 81u);
+        uint32_t ma = (uint32_t)(x >> 40) & 0x7fffffu, mb = (uint32_t)(x * 0x2545F4914F6CDD1Dull >> 41) & 0x7fffffu;
+        if (ea == 167u) ma = 0u;
+        if (eb == 167u) mb = 0u;
+        const float a = __uint_as_float((ea << 23) | ma), b = __uint_as_float((eb << 23) | mb);
+        const float want = a / b;
+        const float got = window_div(a, b);
+        bad += (__float_as_uint(want) != __float_as_uint(got)) ? 1ull : 0ull;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// ------------------------------------------------------------------------------------------
 //  Multi-tensor batch (SURVEY f-4): the 4 / 12 / 40 weight-sized tensors a training step fake-quantises
 //  are latency-bound one by one (each launch costs more than its work).  A batch is a device-resident
 //  table of tasks; ONE launch covers every tensor's traversal (each 256-thread block finds its task by
@@ -1295,7 +1375,7 @@ static int bind_ws(Params& p, const Plan& pl, void* ws, size_t ws_bytes) {
 }
 
 template <int OP>
-static int launch_traverse(const Plan& pl, const Params& p, hipStream_t st) {
+static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
     using O = OpT<OP>;
     if (pl.mode == MODE_ROW_BIG) {
         const int64_t units = pl.R * pl.nc;
@@ -1306,6 +1386,22 @@ static int launch_traverse(const Plan& pl, const Params& p, hipStream_t st) {
         const int grid3d = (p.G <= 65535 && outer_f <= 65535 && pl.R == outer_f * p.G) ? 1 : 0;
         const dim3 grid = grid3d ? dim3((unsigned)pl.nc, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)units);
         const bool nt = vec && (double)pl.R * (double)pl.L * 4.0 >= (double)kNtBytes;
+        // lambda >= 4e-4 (tmode >= 1): two float4 per thread, see row_stream_body.  The unit doubles, so the chunk
+        // count halves; the workspace bound (computed for one float4 per thread) still holds.
+        const bool u2 = (OP == OP_BWD || OP == OP_FUSED) && p.tmode >= 1 && vec && nt && pl.bs == 512;
+        if (u2) {
+            const int64_t nc2 = ceil_div(pl.L, (int64_t)pl.bs * 8);
+            const dim3 grid2 = grid3d ? dim3((unsigned)nc2, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)(pl.R * nc2));
+            hipLaunchKernelGGL((k_row_stream<OP, 4, 512, 1, 2>), grid2, dim3(512), 0, st, p, pl.L, nc2, grid3d);
+            // the finalize that follows must walk the partial layout this launch produced
+            pl.CH = pl.bs * 8;
+            pl.nc = nc2;
+            pl.np = pl.R * nc2;
+            pl.gstride = nc2;
+            pl.stride1 = p.G * nc2;
+            pl.n2 = nc2;
+            return check_hip("traversal launch");
+        }
 #define LQ_LAUNCH_STREAM(VEC_, BS_, NT_) \
         hipLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_>), grid, dim3(BS_), 0, st, p, pl.L, pl.nc, grid3d)
         if (vec) {
@@ -1837,6 +1933,14 @@ int lq_batch_scale_adam(const lq_batch* b, double lr, double beta1, double beta2
                        (float)beta1, (float)beta2, lr, beta1, beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
                        step_dev, step, mode);
     return check_hip("batch adam launch");
+}
+
+int lq_selftest_ratio_division(uint64_t seed, uint32_t blocks, uint32_t pairs_per_thread, uint64_t* mismatches_dev, void* stream) {
+    if (!mismatches_dev || !aligned(mismatches_dev, 8)) return fail(LQ_EINVAL, "lq_selftest_ratio_division: mismatches_dev must be an 8-byte aligned device pointer");
+    if (blocks == 0 || pairs_per_thread == 0) return fail(LQ_EINVAL, "lq_selftest_ratio_division: empty test");
+    hipLaunchKernelGGL(k_selftest_ratio_div, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, seed, pairs_per_thread,
+                       reinterpret_cast<unsigned long long*>(mismatches_dev));
+    return check_hip("selftest launch");
 }
 
 }  // extern "C"

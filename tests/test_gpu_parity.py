@@ -249,3 +249,14 @@ def test_c_abi_without_python(dev, tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "0 mismatches" in res.stdout
+
+
+def test_window_division_selftest(dev):
+    """2^33 random in-window (a, b) pairs: the packed rcp+fma ratio division == IEEE '/' bit for bit on this device."""
+    from learned_quantization_amd import _hip
+    lib = _hip.load()
+    bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    for seed in (1, 0xDEADBEEF, 20240229, 7):
+        _hip.check(lib.lq_selftest_ratio_division(seed, 8192, 1024, bad.data_ptr(), None), "selftest")
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
