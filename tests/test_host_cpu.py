@@ -192,3 +192,22 @@ def test_fast_division_sequence_is_exact_on_cpu(tmp_path):
                            os.path.join(ROOT, "tests", "tools", "check_fast_div.c"), "-lm"])
     res = subprocess.run([exe, "8", "2024"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and " 0 mismatches" in res.stdout, res.stdout + res.stderr
+
+
+def test_batch_abi_validation_without_gpu():
+    """lq_batch_* argument checks that return before any HIP call."""
+    import ctypes
+    lib = _hip.load()
+    handle = ctypes.c_void_p()
+    assert lib.lq_batch_create(None, 1, ctypes.byref(handle)) == -1
+    arr = (_hip.TensorDesc * 1)()
+    assert lib.lq_batch_create(arr, 0, ctypes.byref(handle)) == -1
+    assert lib.lq_batch_create(arr, 100000, ctypes.byref(handle)) == -1
+    assert b"1..256" in lib.lq_last_error()
+    arr[0] = _hip.TensorDesc(None, None, None, None, None, None, None, 1, 1, 16, 1e-3, 0.0)
+    assert lib.lq_batch_create(arr, 1, ctypes.byref(handle)) == -1            # NULL P/s/out
+    assert lib.lq_batch_forward(None, None) == -1
+    assert lib.lq_batch_scale_grad(None, None, None, 0, None) == -1
+    assert lib.lq_batch_workspace_bytes(None) == 0
+    assert lib.lq_batch_destroy(None) == 0
+    assert lib.lq_selftest_ratio_division(1, 0, 1, None, None) == -1
