@@ -740,7 +740,7 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params 
 //  Traversal 2 -- "row small": rows of length L < 1024.  A team of 2^lpr_log2 lanes (<= 64,
 //  inside one wave) owns a row; 256 >> lpr_log2 rows per block; one partial per row.
 // ------------------------------------------------------------------------------------------
-template <int OP>
+template <int OP, int VEC>
 __device__ __forceinline__ void row_small_body(const Params& p, int64_t R, int L, int lpr_log2, int64_t blk) {
     using O = OpT<OP>;
     const int lpr = 1 << lpr_log2;
@@ -752,12 +752,33 @@ __device__ __forceinline__ void row_small_body(const Params& p, int64_t R, int L
     if (valid) {
         const Ctx ctx = O::ctx(p, row % p.G);
         const int64_t base = row * (int64_t)L;
+        if (VEC == 4) {   // L % 4 == 0 and 16-B aligned bases: every row starts on a float4 boundary
+            const int L4 = L >> 2;
+#pragma unroll 2
+            for (int j = lane; j < L4; j += lpr) {
+                const int64_t i = base + (int64_t)j * 4;
+                const float4 x = *reinterpret_cast<const float4*>(p.P + i);
+                float4 d = x;
+                if (O::kDy) d = *reinterpret_cast<const float4*>(p.dy + i);
+                float4 r;
+                if constexpr (O::kVec4) {
+                    r = O::elem4(p, ctx, i, x, d, acc);
+                } else {
+                    r.x = O::elem(p, ctx, i + 0, x.x, O::kDy ? d.x : 0.f, acc);
+                    r.y = O::elem(p, ctx, i + 1, x.y, O::kDy ? d.y : 0.f, acc);
+                    r.z = O::elem(p, ctx, i + 2, x.z, O::kDy ? d.z : 0.f, acc);
+                    r.w = O::elem(p, ctx, i + 3, x.w, O::kDy ? d.w : 0.f, acc);
+                }
+                if (O::kStore) *reinterpret_cast<float4*>(p.out + i) = r;
+            }
+        } else {
 #pragma unroll 4
-        for (int j = lane; j < L; j += lpr) {
-            const float x = p.P[base + j];
-            const float d = O::kDy ? p.dy[base + j] : 0.f;
-            float r = O::elem(p, ctx, base + j, x, d, acc);
-            if (O::kStore) p.out[base + j] = r;
+            for (int j = lane; j < L; j += lpr) {
+                const float x = p.P[base + j];
+                const float d = O::kDy ? p.dy[base + j] : 0.f;
+                float r = O::elem(p, ctx, base + j, x, d, acc);
+                if (O::kStore) p.out[base + j] = r;
+            }
         }
     }
     if (O::kReduce) {
@@ -766,9 +787,9 @@ __device__ __forceinline__ void row_small_body(const Params& p, int64_t R, int L
     }
 }
 
-template <int OP>
+template <int OP, int VEC>
 __global__ __launch_bounds__(kBlock) void k_row_small(Params p, int64_t R, int L, int lpr_log2) {
-    row_small_body<OP>(p, R, L, lpr_log2, (int64_t)blockIdx.x);
+    row_small_body<OP, VEC>(p, R, L, lpr_log2, (int64_t)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1286,7 +1307,8 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
         if (t.vec) row_stream_body<OP, 4, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
         else row_stream_body<OP, 1, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
     } else if (t.mode == 1) {
-        row_small_body<OP>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
+        if (t.vec) row_small_body<OP, 4>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
+        else row_small_body<OP, 1>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
     } else {
         col_body<OP>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b);
     }
@@ -1493,6 +1515,17 @@ static int bind_ws(Params& p, const Plan& pl, void* ws, size_t ws_bytes) {
     return LQ_OK;
 }
 
+// row-small: lanes per row.  Scalar form: pow2floor(max(L/2,1)) (plan); float4 form: pow2ceil(L/4), both <= 64.
+static int row_small_lpr_log2_vec(int64_t L) {
+    const int64_t l4 = L / 4;
+    int lg = 0;
+    while ((1 << lg) < l4 && lg < 6) ++lg;
+    return lg;
+}
+static bool row_small_vec(const Plan& pl, const void* P, const void* dy, const void* out) {
+    return pl.L % 4 == 0 && pl.L >= 8 && aligned(P, 16) && (!dy || aligned(dy, 16)) && (!out || aligned(out, 16));
+}
+
 // column-mode kernel variant and blocks along the columns: 0 = periodic (C <= 64), 4 = float4 tile, 1 = scalar tile
 static void col_variant(const Plan& pl, const void* P, const void* dy, const void* out, int& variant, int64_t& nbx) {
     if (pl.C <= 64) {
@@ -1555,10 +1588,12 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         }
 #undef LQ_LAUNCH_STREAM
     } else if (pl.mode == MODE_ROW_SMALL) {
-        const int rpb = kBlock >> pl.lpr_log2;
-        const int64_t blocks = ceil_div(pl.R, rpb);
+        const bool vec = row_small_vec(pl, p.P, O::kDy ? p.dy : nullptr, O::kStore ? p.out : nullptr);
+        const int lg = vec ? row_small_lpr_log2_vec(pl.L) : pl.lpr_log2;
+        const int64_t blocks = ceil_div(pl.R, kBlock >> lg);
         if (blocks > 2147483647ll) return fail(LQ_EINVAL, "too many blocks (%lld)", (long long)blocks);
-        hipLaunchKernelGGL((k_row_small<OP>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L, pl.lpr_log2);
+        if (vec) hipLaunchKernelGGL((k_row_small<OP, 4>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L, lg);
+        else hipLaunchKernelGGL((k_row_small<OP, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L, lg);
     } else {
         int variant;
         int64_t nbx;
@@ -1917,7 +1952,9 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, uint32_t& block
         // float4 path: forward needs P and out 16-byte aligned; backward needs P (dy is checked at every launch)
         t.vec = ((pl.L % 4 == 0 || pl.R == 1) && aligned(d.P, 16) && (bwd || aligned(d.out, 16))) ? 1 : 0;
     } else if (pl.mode == MODE_ROW_SMALL) {
-        blocks = ceil_div(pl.R, kBlock >> pl.lpr_log2);
+        t.vec = row_small_vec(pl, d.P, nullptr, bwd ? nullptr : d.out) ? 1 : 0;
+        if (t.vec) t.lpr_log2 = row_small_lpr_log2_vec(pl.L);
+        blocks = ceil_div(pl.R, kBlock >> t.lpr_log2);
     } else {
         blocks = t.nbx * pl.ysplit;
     }
@@ -2047,7 +2084,7 @@ int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, siz
         const float* d = dy ? dy[b->bwd_index[i]] : b->bwd_h[i].p.dy;
         if (!d) return fail(LQ_EINVAL, "lq_batch_scale_grad: no upstream gradient for tensor %d", b->bwd_index[i]);
         if (!aligned(d, 4)) return fail(LQ_EALIGN, "lq_batch_scale_grad: dy of tensor %d misaligned", b->bwd_index[i]);
-        if (((b->bwd_h[i].mode == MODE_ROW_BIG && b->bwd_h[i].vec) || (b->bwd_h[i].mode == MODE_COL && b->bwd_h[i].col_variant == 4)) &&
+        if (((b->bwd_h[i].mode != MODE_COL && b->bwd_h[i].vec) || (b->bwd_h[i].mode == MODE_COL && b->bwd_h[i].col_variant == 4)) &&
             !aligned(d, 16))
             all_aligned = false;
         pk.dy[i] = d;
