@@ -811,7 +811,7 @@ __device__ __forceinline__ void col_cross_wave(Acc* lds, const Acc& mine, int sl
     lds[(threadIdx.x >> 6) * slots + slot] = mine;
 }
 
-template <int OP, int VW>
+template <int OP, int VW, int NT>
 __device__ __forceinline__ void col_tile_body(const Params& p, int64_t C, int64_t RB, int64_t bx, int64_t by) {
     using O = OpT<OP>;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -834,10 +834,10 @@ __device__ __forceinline__ void col_tile_body(const Params& p, int64_t C, int64_
                 const int64_t rr = (r + 4 * u < r1) ? r + 4 * u : r1 - 1;     // clamp: loads stay unconditional
                 const int64_t i = rr * C + col0;
                 if (VW == 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(p.P + i);
+                    const float4 v = load4<NT>(p.P + i);
                     x[u][0] = v.x; x[u][1 % VW] = v.y; x[u][2 % VW] = v.z; x[u][3 % VW] = v.w;
                     if (O::kDy) {
-                        const float4 e = *reinterpret_cast<const float4*>(p.dy + i);
+                        const float4 e = load4<NT>(p.dy + i);
                         d[u][0] = e.x; d[u][1 % VW] = e.y; d[u][2 % VW] = e.z; d[u][3 % VW] = e.w;
                     }
                 } else {
@@ -853,7 +853,7 @@ __device__ __forceinline__ void col_tile_body(const Params& p, int64_t C, int64_
 #pragma unroll
                     for (int k = 0; k < VW; ++k) o[k] = O::elem(p, ctx[k], i + k, x[u][k], O::kDy ? d[u][k] : 0.f, acc[k]);
                     if (O::kStore) {
-                        if (VW == 4) *reinterpret_cast<float4*>(p.out + i) = make_float4(o[0], o[1 % VW], o[2 % VW], o[3 % VW]);
+                        if (VW == 4) store4<NT>(p.out + i, make_float4(o[0], o[1 % VW], o[2 % VW], o[3 % VW]));
                         else p.out[i] = o[0];
                     }
                 }
@@ -923,15 +923,17 @@ __device__ __forceinline__ void col_small_body(const Params& p, int C, int64_t R
     }
 }
 
-// variant: 0 = periodic (C <= 64), 1 = tile with scalar columns, 4 = tile with float4 (4 columns per lane)
+// variant: 0 = periodic (C <= 64), 1 = tile with scalar columns, 4 = tile with float4 (4 columns per lane),
+// 5 = float4 tile with nontemporal accesses (tensors >= 64 MiB)
 template <int OP>
 __device__ __forceinline__ void col_body(const Params& p, int64_t C, int64_t RB, int64_t nbx, int variant, int64_t b) {
     if (variant == 0) {
         col_small_body<OP>(p, (int)C, RB, b);
     } else {
         const int64_t by = b / nbx, bx = b - by * nbx;
-        if (variant == 4) col_tile_body<OP, 4>(p, C, RB, bx, by);
-        else col_tile_body<OP, 1>(p, C, RB, bx, by);
+        if (variant == 5) col_tile_body<OP, 4, 1>(p, C, RB, bx, by);
+        else if (variant == 4) col_tile_body<OP, 4, 0>(p, C, RB, bx, by);
+        else col_tile_body<OP, 1, 0>(p, C, RB, bx, by);
     }
 }
 
@@ -1532,7 +1534,7 @@ static void col_variant(const Plan& pl, const void* P, const void* dy, const voi
         variant = 0;
         nbx = 1;
     } else if (pl.C % 4 == 0 && aligned(P, 16) && (!dy || aligned(dy, 16)) && (!out || aligned(out, 16))) {
-        variant = 4;
+        variant = ((double)pl.C * (double)pl.ysplit * (double)pl.rps * 4.0 >= (double)kNtBytes) ? 5 : 4;
         nbx = ceil_div(pl.C, 256);
     } else {
         variant = 1;
@@ -2084,7 +2086,7 @@ int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, siz
         const float* d = dy ? dy[b->bwd_index[i]] : b->bwd_h[i].p.dy;
         if (!d) return fail(LQ_EINVAL, "lq_batch_scale_grad: no upstream gradient for tensor %d", b->bwd_index[i]);
         if (!aligned(d, 4)) return fail(LQ_EALIGN, "lq_batch_scale_grad: dy of tensor %d misaligned", b->bwd_index[i]);
-        if (((b->bwd_h[i].mode != MODE_COL && b->bwd_h[i].vec) || (b->bwd_h[i].mode == MODE_COL && b->bwd_h[i].col_variant == 4)) &&
+        if (((b->bwd_h[i].mode != MODE_COL && b->bwd_h[i].vec) || (b->bwd_h[i].mode == MODE_COL && b->bwd_h[i].col_variant >= 4)) &&
             !aligned(d, 16))
             all_aligned = false;
         pk.dy[i] = d;
