@@ -188,6 +188,17 @@ int lq_batch_scale_grad(const lq_batch* batch, const float* const* dy, void* ws,
 int lq_batch_scale_adam(const lq_batch* batch, double lr, double beta1, double beta2, double eps, int64_t step,
                         const int64_t* step_dev, int mode, void* stream);
 
+/* ---- integer-view range and histogram (tracking callbacks) -----------------------------------------
+ * The reference's callbacks pull floor(P/s) to the host and run np.unique on it every epoch
+ *   CIFAR-10/nested_quantization_layer/custom_components/custom_callbacks.py:85-96, 131-207.
+ * lq_q_minmax: minmax_dev[0] = min q, minmax_dev[1] = max q over the tensor (int32; the caller initialises the
+ *   pair to {INT32_MAX, INT32_MIN}; NaN/Inf/out-of-int32 quotients are skipped).
+ * lq_q_histogram: bins_dev[q - qmin] += count for qmin <= q < qmin + nbins (uint32 bins, zeroed by the caller).
+ *   #unique = number of non-zero bins; (value, count) pairs = the non-zero bins.  Integer atomics: exact.      */
+int lq_q_minmax(const float* P, const float* s, int32_t* minmax_dev, int64_t outer, int64_t G, int64_t inner, void* stream);
+int lq_q_histogram(const float* P, const float* s, int32_t qmin, int64_t nbins, uint32_t* bins_dev,
+                   int64_t outer, int64_t G, int64_t inner, void* stream);
+
 /* ---- device self-test -------------------------------------------------------------------
  * Compares the kernels' in-window ratio division (rcp + Newton + fma chain, see lq_kernels.hip window_div)
  * with the IEEE `/` on blocks*256*pairs_per_thread pseudo-random operand pairs in [2^-40, 2^40]; ADDS the

@@ -11,7 +11,7 @@ from .layers import (CustomConv2DLayer, CustomConv2DLayerNoBias, CustomDenseLaye
                      reset_layer_names)
 from .losses import SCCEDifference, SCCEInverse, SCCEMaxBin, sparse_categorical_crossentropy
 from .ops import (difference_term, fq_forward, fq_fwd_bwd_fused, fq_scale_grad, inverse_term, maxbin_term,
-                  my_custom_gradient, q_absmax_over_axis, quantized_integers)
+                  my_custom_gradient, q_absmax_over_axis, q_unique, quantized_integers)
 from .optim import ScaleAdam, apply_constraints, non_scale_parameters, scale_parameters
 from .ddp import DataParallel, GradBucket
 from .batch import BatchedScaleAdam, FakeQuantBatch

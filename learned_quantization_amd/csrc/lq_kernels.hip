@@ -1229,6 +1229,65 @@ __global__ void k_q_absmax_axis(const float* P, const float* s, float* result, i
 }
 
 // ------------------------------------------------------------------------------------------
+//  Integer-view statistics for the tracking callbacks (custom_callbacks.py:85-96, 131-207): range and
+//  histogram of q = floor(P/s).  Integer atomics only -> exact and independent of arrival order.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool q_as_int(float x, float sg, int32_t& qi) {
+    const float q = floorf(x / sg);
+    if (!(fabsf(q) < 2147483520.0f)) return false;   // NaN / Inf / beyond int32: not counted
+    qi = (int32_t)q;
+    return true;
+}
+
+__global__ __launch_bounds__(kBlock) void k_q_minmax(const float* __restrict__ P, const float* __restrict__ s, int32_t* minmax,
+                                                     int64_t n, int64_t G, int64_t inner) {
+    int32_t lo = INT32_MAX, hi = INT32_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        int32_t qi;
+        if (q_as_int(P[i], s[(i / inner) % G], qi)) {
+            lo = qi < lo ? qi : lo;
+            hi = qi > hi ? qi : hi;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const int32_t l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (lo != INT32_MAX) atomicMin(&minmax[0], lo);
+        if (hi != INT32_MIN) atomicMax(&minmax[1], hi);
+    }
+}
+
+constexpr int kHistLds = 4096;   // bins privatised in LDS per block (the trained models use a few dozen integers)
+
+__global__ __launch_bounds__(kBlock) void k_q_histogram(const float* __restrict__ P, const float* __restrict__ s, int32_t qmin,
+                                                        int64_t nbins, uint32_t* bins, int64_t n, int64_t G, int64_t inner) {
+    __shared__ uint32_t lh[kHistLds];
+    const bool priv = nbins <= kHistLds;
+    if (priv) {
+        for (int b = threadIdx.x; b < (int)nbins; b += kBlock) lh[b] = 0u;
+        __syncthreads();
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        int32_t qi;
+        if (!q_as_int(P[i], s[(i / inner) % G], qi)) continue;
+        const int64_t b = (int64_t)qi - (int64_t)qmin;
+        if (b < 0 || b >= nbins) continue;
+        if (priv) atomicAdd(&lh[b], 1u);
+        else atomicAdd(&bins[b], 1u);
+    }
+    if (priv) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < (int)nbins; b += kBlock) {
+            const uint32_t c = lh[b];
+            if (c) atomicAdd(&bins[b], c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 //  Device self-test of window_div against the IEEE division (random in-window operand pairs).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_selftest_ratio_div(uint64_t seed, uint32_t per_thread, unsigned long long* mismatches) {
@@ -2119,6 +2178,34 @@ int lq_selftest_ratio_division(uint64_t seed, uint32_t blocks, uint32_t pairs_pe
     hipLaunchKernelGGL(k_selftest_ratio_div, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, seed, pairs_per_thread,
                        reinterpret_cast<unsigned long long*>(mismatches_dev));
     return check_hip("selftest launch");
+}
+
+int lq_q_minmax(const float* P, const float* s, int32_t* minmax_dev, int64_t outer, int64_t G, int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(minmax_dev);
+    const int64_t n = outer * G * inner;
+    int64_t blocks = ceil_div(n, (int64_t)kBlock * 8);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_q_minmax, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, P, s, minmax_dev, n, G, inner);
+    return check_hip("q minmax launch");
+}
+
+int lq_q_histogram(const float* P, const float* s, int32_t qmin, int64_t nbins, uint32_t* bins_dev, int64_t outer, int64_t G,
+                   int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    if (nbins <= 0) return fail(LQ_EINVAL, "lq_q_histogram: nbins must be positive");
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(bins_dev);
+    const int64_t n = outer * G * inner;
+    int64_t blocks = ceil_div(n, (int64_t)kBlock * 16);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_q_histogram, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, P, s, qmin, nbins, bins_dev, n, G, inner);
+    return check_hip("q histogram launch");
 }
 
 }  // extern "C"

@@ -122,6 +122,32 @@ def q_absmax_over_axis(parameter: torch.Tensor, scale: torch.Tensor, axis: int) 
     return res
 
 
+_MAX_BINS = 1 << 26   # 256 MiB of uint32 bins; beyond that the integers are not "a few quantisation levels"
+
+
+def q_unique(parameter: torch.Tensor, scale: torch.Tensor):
+    """np.unique(floor(P/s), return_counts=True) of the callbacks (custom_callbacks.py:92, 142) computed on the
+    device: range by lq_q_minmax, counts by lq_q_histogram.  Returns (values int32, counts int64), both on the device.
+    One small device->host read (the range) is needed to size the histogram -- this is a per-epoch statistic."""
+    lib = _hip.load()
+    p = _hip.require_device_f32(parameter, "parameter")
+    s = _hip.require_device_f32(scale, "scale")
+    outer, G, inner = _desc(p, s)
+    st = _hip.stream_ptr(p.device)
+    mm = torch.tensor([2 ** 31 - 1, -(2 ** 31)], dtype=torch.int32, device=p.device)
+    _hip.check(lib.lq_q_minmax(_hip.ptr(p), _hip.ptr(s), _hip.ptr(mm), outer, G, inner, st), "lq_q_minmax")
+    lo, hi = (int(v) for v in mm.tolist())
+    if lo > hi:                                            # nothing countable (all NaN/Inf)
+        return (torch.empty(0, dtype=torch.int32, device=p.device), torch.empty(0, dtype=torch.int64, device=p.device))
+    nbins = hi - lo + 1
+    if nbins > _MAX_BINS:
+        raise ValueError(f"integer range [{lo}, {hi}] too wide for a histogram ({nbins} bins)")
+    bins = torch.zeros(nbins, dtype=torch.int32, device=p.device)
+    _hip.check(lib.lq_q_histogram(_hip.ptr(p), _hip.ptr(s), lo, nbins, _hip.ptr(bins), outer, G, inner, st), "lq_q_histogram")
+    nz = torch.nonzero(bins, as_tuple=False).flatten()
+    return (nz + lo).to(torch.int32), bins[nz].to(torch.int64)
+
+
 def min_value_project_(w: torch.Tensor, min_value: float) -> torch.Tensor:
     """In-place MinValueConstraint: w <- max(w, min_value)  (custom_layers.py:42-43)."""
     lib = _hip.load()

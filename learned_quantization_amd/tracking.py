@@ -7,7 +7,8 @@ directory layout (``on_epoch_end`` / ``on_train_end`` / ``on_train_begin``) and 
 (process_file_logged_per_epoch, plot_scripts.py:13-38) keep working.
 
 The statistics that define the Pareto axes are computed on the GPU -- ``floor(P/s)`` by the HIP kernel K1,
-``max|q|`` over axis 1 by ``lq_q_absmax_over_axis``, unique counts by a device sort -- and only the
+``max|q|`` over axis 1 by ``lq_q_absmax_over_axis``, unique values/counts by ``lq_q_minmax`` + ``lq_q_histogram``
+(LDS-privatised integer histogram) -- and only the
 results cross PCIe.  The reference's per-epoch dump of every raw kernel value (:52-66) is opt-in
 (``dump_values=True``): it is tens of MB of text per epoch and not needed by the Pareto plots.
 """
@@ -65,8 +66,8 @@ class NestedScaleTrackingCallback:
         qb = ops.quantized_integers(self.layer.b.data, self.b_scale.data, torch.float32)
         axis = 1 if self.param.dim() > 1 else 0
         return {
-            "unique_k": int(torch.unique(qk).numel()),
-            "unique_b": int(torch.unique(qb).numel()),
+            "unique_k": int(ops.q_unique(self.param.data, self.k_scale.data)[0].numel()),
+            "unique_b": int(ops.q_unique(self.layer.b.data, self.b_scale.data)[0].numel()),
             "max_k": ops.q_absmax_over_axis(self.param.data, self.k_scale.data, axis).flatten().cpu(),
             "max_b": float(qb.abs().max()),
         }
@@ -98,9 +99,9 @@ class NestedScaleTrackingCallback:
                                               (self.layer.b, self.b_scale, path_b, path_bu)):
             q = ops.quantized_integers(param.data, scale.data, torch.float32).flatten()
             self._append(p_all, None, q.cpu().numpy())
-            u, c = torch.unique(q, return_counts=True)
+            u, c = ops.q_unique(param.data, scale.data)                 # HIP histogram, not a device sort
             with open(p_unique, "a") as f:
-                for value, count in zip(u.cpu().numpy(), c.cpu().numpy()):
+                for value, count in zip(u.cpu().numpy().astype("float32"), c.cpu().numpy()):
                     f.write(f"{value}, {count}\n")
 
     def on_train_end(self, logs=None):

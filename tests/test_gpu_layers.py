@@ -179,3 +179,19 @@ def test_callback_statistic_absmax_over_axis(dev):
     got = lq.q_absmax_over_axis(torch.tensor(k, device=dev), torch.tensor(s, device=dev), axis=1).cpu().numpy()
     want = np.max(np.abs(O.quantized_integers(k, s)), axis=1)     # custom_callbacks.py:98
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("shape,orient,smag", [((3, 3, 8, 16), "channelwise", 1e-2), ((784, 128), "rowwise", 1.1920929e-05),
+                                               ((50,), "scalar", 1e-3), ((64, 3, 31, 31), "columnwise", 0.7)])
+def test_q_unique_matches_numpy_unique(dev, shape, orient, smag):
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(4)
+    P = rng.normal(0, 0.05, size=shape).astype(np.float32)
+    if len(shape) == 4 and shape[0] == 64:
+        P = (P * 2000).astype(np.float32)
+    s = (rng.uniform(0.5, 2.0, size=O.scale_shape(shape, orient)) * smag).astype(np.float32)
+    vals, counts = lq.q_unique(torch.tensor(P, device=dev), torch.tensor(s, device=dev))
+    u, c = np.unique(O.quantized_integers(P, s), return_counts=True)      # custom_callbacks.py:92
+    np.testing.assert_array_equal(vals.cpu().numpy(), u.astype(np.int32))
+    np.testing.assert_array_equal(counts.cpu().numpy(), c)
+    assert int(counts.sum()) == P.size
