@@ -1,0 +1,217 @@
+// lq_aux_kernels.hpp -- scale-sized vector kernels (K5c, K6), integer-view statistics, device self-test
+#ifndef LQ_AUX_KERNELS_HPP_
+#define LQ_AUX_KERNELS_HPP_
+#include "lq_traverse.hpp"
+
+namespace lq {
+
+// ------------------------------------------------------------------------------------------
+//  Small vector kernels (scale-sized data).
+// ------------------------------------------------------------------------------------------
+// mode 0: out = mean(v[0..n))      mode 1: out = mean(1 / where(v==0, eps, v))
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_vec_mean(const float* v, int64_t n, float* out) {
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+        float x = v[i];
+        if (MODE == 1) {
+            float nz = (x == 0.0f) ? kEpsF32 : x;     // custom_loss_functions.py:252
+            x = 1.0f / nz;                            // :255
+        }
+        acc += (double)x;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ double lds[kWavesPerBlock];
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+        for (int w = 1; w < kWavesPerBlock; ++w) t += lds[w];
+        out[0] = (float)(t / (double)n);
+    }
+}
+
+__global__ void k_maxbin_ds(const float* s, const float* mb, const float* c_dev, float c_scale, float* ds, int64_t G) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const float up = c_dev[0] * c_scale;
+    // sum over ties of -(g_i) * t / s with g_i = up/(G*ties): = -(up/G) * mb / s
+    ds[g] = -((up / (float)G) * mb[g]) / s[g];
+}
+
+__global__ void k_inverse_bwd(const float* s, const float* c_dev, float c_scale, float* ds, int64_t G) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const float up = c_dev[0] * c_scale;
+    const float sg = s[g];
+    // d/ds mean(1/s) = -1/(G s^2); tf.where routes no gradient into s where s == 0
+    ds[g] = (sg == 0.0f) ? 0.0f : -((up / (float)G) / sg) / sg;
+}
+
+// f0..f3 are host-computed factors (python-double arithmetic rounded to fp32, as Keras / torch do):
+//   keras: f0 = 1-b1, f1 = 1-b2, f2 = alpha = lr*sqrt(1-b2^t)/(1-b1^t), f3 = eps
+//   torch: f0 = 1-b1, f1 = 1-b2, f2 = lr/(1-b1^t), f3 = eps, f4 = sqrt(1-b2^t)
+__global__ void k_adam(float* s, const float* ds, float* m, float* v, int64_t n, float f0, float f1, float f2, float f3,
+                       float f4, float min_value, int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float g = ds[i];
+    float mi = m[i], vi = v[i], w = s[i];
+    mi = mi + (g - mi) * f0;
+    vi = vi + (g * g - vi) * f1;
+    if (mode == LQ_ADAM_KERAS) {
+        w = w - (mi * f2) / (sqrtf(vi) + f3);
+    } else {
+        const float denom = sqrtf(vi) / f4 + f3;
+        w = w - f2 * (mi / denom);
+    }
+    w = (w < min_value) ? min_value : w;   // MinValueConstraint: max(w, min_value); NaN stays NaN
+    m[i] = mi;
+    v[i] = vi;
+    s[i] = w;
+}
+
+// Same update, with the 1-based step read from device memory (hipGraph-capturable: nothing about the
+// step is baked into the launch).  Keras mode forms beta^t in fp32 like tf.pow; torch mode in fp64.
+__global__ void k_adam_dev(float* s, const float* ds, float* m, float* v, int64_t n, float lr, float b1, float b2, double lr_d,
+                           double b1_d, double b2_d, float f0, float f1, float eps, const int64_t* step_dev, float min_value,
+                           int mode) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t step = step_dev[0];
+    const float g = ds[i];
+    float mi = m[i], vi = v[i], w = s[i];
+    mi = mi + (g - mi) * f0;
+    vi = vi + (g * g - vi) * f1;
+    if (mode == LQ_ADAM_KERAS) {
+        const float b1p = powf(b1, (float)step), b2p = powf(b2, (float)step);
+        const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+        w = w - (mi * alpha) / (sqrtf(vi) + eps);
+    } else {
+        const double bc1 = 1.0 - pow(b1_d, (double)step), bc2 = 1.0 - pow(b2_d, (double)step);
+        const float step_size = (float)(lr_d / bc1);
+        const float denom = sqrtf(vi) / (float)sqrt(bc2) + eps;
+        w = w - step_size * (mi / denom);
+    }
+    w = (w < min_value) ? min_value : w;
+    m[i] = mi;
+    v[i] = vi;
+    s[i] = w;
+}
+
+__global__ void k_min_project(float* w, int64_t n, float min_value) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = w[i];
+    w[i] = (x < min_value) ? min_value : x;   // tf.maximum(w, min_value); NaN propagates
+}
+
+// result[a, b] = max over the middle axis of |floor(P/s)| for a tensor viewed (pre, n_axis, post)
+__global__ void k_q_absmax_axis(const float* P, const float* s, float* result, int64_t pre, int64_t n_axis, int64_t post,
+                                int64_t G, int64_t inner) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pre * post) return;
+    const int64_t a = t / post, b = t - a * post;
+    uint32_t best = 0u;
+    for (int64_t k = 0; k < n_axis; ++k) {
+        const int64_t i = (a * n_axis + k) * post + b;
+        Ctx c;
+        c.s = s[(i / inner) % G];
+        c.r = 0.f;
+        c.fast = 0;
+        c.lam_hi = 0.f;
+        c.sure_ok = 0;
+        c.k0 = c.k1 = 0.f;
+        float q, o;
+        fq_core(P[i], c, q, o);
+        const uint32_t bits = __float_as_uint(fabsf(q));
+        best = bits > best ? bits : best;
+    }
+    result[t] = __uint_as_float(best);
+}
+
+// ------------------------------------------------------------------------------------------
+//  Integer-view statistics for the tracking callbacks (custom_callbacks.py:85-96, 131-207): range and
+//  histogram of q = floor(P/s).  Integer atomics only -> exact and independent of arrival order.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool q_as_int(float x, float sg, int32_t& qi) {
+    const float q = floorf(x / sg);
+    if (!(fabsf(q) < 2147483520.0f)) return false;   // NaN / Inf / beyond int32: not counted
+    qi = (int32_t)q;
+    return true;
+}
+
+__global__ __launch_bounds__(kBlock) void k_q_minmax(const float* __restrict__ P, const float* __restrict__ s, int32_t* minmax,
+                                                     int64_t n, int64_t G, int64_t inner) {
+    int32_t lo = INT32_MAX, hi = INT32_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        int32_t qi;
+        if (q_as_int(P[i], s[(i / inner) % G], qi)) {
+            lo = qi < lo ? qi : lo;
+            hi = qi > hi ? qi : hi;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const int32_t l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (lo != INT32_MAX) atomicMin(&minmax[0], lo);
+        if (hi != INT32_MIN) atomicMax(&minmax[1], hi);
+    }
+}
+
+constexpr int kHistLds = 4096;   // bins privatised in LDS per block (the trained models use a few dozen integers)
+
+__global__ __launch_bounds__(kBlock) void k_q_histogram(const float* __restrict__ P, const float* __restrict__ s, int32_t qmin,
+                                                        int64_t nbins, uint32_t* bins, int64_t n, int64_t G, int64_t inner) {
+    __shared__ uint32_t lh[kHistLds];
+    const bool priv = nbins <= kHistLds;
+    if (priv) {
+        for (int b = threadIdx.x; b < (int)nbins; b += kBlock) lh[b] = 0u;
+        __syncthreads();
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        int32_t qi;
+        if (!q_as_int(P[i], s[(i / inner) % G], qi)) continue;
+        const int64_t b = (int64_t)qi - (int64_t)qmin;
+        if (b < 0 || b >= nbins) continue;
+        if (priv) atomicAdd(&lh[b], 1u);
+        else atomicAdd(&bins[b], 1u);
+    }
+    if (priv) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < (int)nbins; b += kBlock) {
+            const uint32_t c = lh[b];
+            if (c) atomicAdd(&bins[b], c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Device self-test of window_div against the IEEE division (random in-window operand pairs).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_selftest_ratio_div(uint64_t seed, uint32_t per_thread, unsigned long long* mismatches) {
+    uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * ((uint64_t)blockIdx.x * kBlock + threadIdx.x + 1));
+    unsigned long long bad = 0;
+    for (uint32_t k = 0; k < per_thread; ++k) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        // exponents 87..167 (2^-40 .. 2^40), random mantissas; the top of the window is clamped to exactly 2^40
+        uint32_t ea = 87u + (uint32_t)((x >> 8) % 81u), eb = 87u + (uint32_t)((x >> 24) % 81u);
+        uint32_t ma = (uint32_t)(x >> 40) & 0x7fffffu, mb = (uint32_t)(x * 0x2545F4914F6CDD1Dull >> 41) & 0x7fffffu;
+        if (ea == 167u) ma = 0u;
+        if (eb == 167u) mb = 0u;
+        const float a = __uint_as_float((ea << 23) | ma), b = __uint_as_float((eb << 23) | mb);
+        const float want = a / b;
+        const float got = window_div(a, b);
+        bad += (__float_as_uint(want) != __float_as_uint(got)) ? 1ull : 0ull;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+}  // namespace lq
+
+#endif

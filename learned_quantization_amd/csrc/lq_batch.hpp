@@ -1,0 +1,135 @@
+// lq_batch.hpp -- device side of the multi-tensor batch (task table, batch kernels)
+#ifndef LQ_BATCH_HPP_
+#define LQ_BATCH_HPP_
+#include "lq_aux_kernels.hpp"
+
+namespace lq {
+
+// ------------------------------------------------------------------------------------------
+//  Multi-tensor batch (SURVEY f-4): the 4 / 12 / 40 weight-sized tensors a training step fake-quantises
+//  are latency-bound one by one (each launch costs more than its work).  A batch is a device-resident
+//  table of tasks; ONE launch covers every tensor's traversal (each 256-thread block finds its task by
+//  binary search over the block prefix) and ONE launch finalizes every group of every tensor.  The per-
+//  tensor code is exactly the single-tensor traversal bodies above, so results are bit-identical.
+// ------------------------------------------------------------------------------------------
+struct Task {
+    Params p;                 // pa/pb/pc are rebound to the batch workspace inside the kernel
+    float* ds;                // scale gradient output [G]
+    int mode, vec, lpr_log2, pad0;
+    int64_t R, L, nc;         // row modes (block size 256)
+    int64_t C, rps, nbx;      // column mode (rps = rows per block, nbx = blocks along the columns)
+    int col_variant, pad1;
+    int64_t np_pad;           // padded partial count; this task's workspace slice is 3 * np_pad words
+    int64_t ws_off;           // offset of the slice in uint32 words
+    int64_t gstride, n1, stride1, n2;   // finalize geometry
+    double count;             // elements per group
+    uint32_t first_block;     // prefix over traversal blocks
+    uint32_t first_group;     // prefix over groups
+};
+
+__device__ __forceinline__ int find_task(const Task* __restrict__ tasks, int ntasks, uint32_t b, bool by_group) {
+    int lo = 0, hi = ntasks - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        const uint32_t first = by_group ? tasks[mid].first_group : tasks[mid].first_block;
+        if (first <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Upstream-gradient pointers change every step (autograd allocates them): they travel in the kernel
+// arguments (captured at launch, no staging buffer to race on), at most kBatchMax per launch.
+constexpr int kBatchMax = 256;
+struct PtrPack {
+    const float* dy[kBatchMax];
+};
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restrict__ tasks, int ntasks, uint32_t* ws, PtrPack pk,
+                                                           int use_pack) {
+    const int ti = find_task(tasks, ntasks, blockIdx.x, false);
+    const Task& t = tasks[ti];
+    Params p = t.p;
+    if (use_pack) p.dy = pk.dy[ti];
+    p.pa = ws + t.ws_off;
+    p.pb = p.pa + t.np_pad;
+    p.pc = reinterpret_cast<float*>(p.pb + t.np_pad);
+    const uint32_t b = blockIdx.x - t.first_block;
+    if (t.mode == 0) {
+        const uint32_t nc = (uint32_t)t.nc;
+        const uint32_t row = b / nc, ck = b - row * nc;
+        const int64_t g = (int64_t)(row % (uint32_t)p.G);
+        if (t.vec) row_stream_body<OP, 4, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
+        else row_stream_body<OP, 1, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
+    } else if (t.mode == 1) {
+        if (t.vec) row_small_body<OP, 4>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
+        else row_small_body<OP, 1>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
+    } else {
+        col_body<OP>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b);
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(64) void k_batch_finalize(const Task* __restrict__ tasks, int ntasks, uint32_t* ws) {
+    const int ti = find_task(tasks, ntasks, blockIdx.x, true);
+    const Task& t = tasks[ti];
+    Params p = t.p;
+    p.pa = ws + t.ws_off;
+    p.pb = p.pa + t.np_pad;
+    p.pc = reinterpret_cast<float*>(p.pb + t.np_pad);
+    FinGeom f;
+    f.groups = p.G;
+    f.gstride = t.gstride;
+    f.n1 = t.n1;
+    f.stride1 = t.stride1;
+    f.n2 = t.n2;
+    f.count = t.count;
+    f.o0 = t.ds;
+    f.o1 = nullptr;
+    f.o2 = nullptr;
+    finalize_block_body<OP, 64>(p, f, (int64_t)(blockIdx.x - t.first_group));
+}
+
+// K6 for every scale of the batch in one launch: block per tensor.
+struct AdamTask {
+    float* s;
+    const float* ds;
+    float* m;
+    float* v;
+    int64_t n;
+    float min_value;
+    int pad;
+};
+
+__global__ __launch_bounds__(kBlock) void k_batch_adam(const AdamTask* __restrict__ tasks, float lr, float b1, float b2, double lr_d,
+                                                       double b1_d, double b2_d, float f0, float f1, float eps,
+                                                       const int64_t* step_dev, int64_t step_host, int mode) {
+    const AdamTask t = tasks[blockIdx.x];
+    const int64_t step = step_dev ? step_dev[0] : step_host;
+    float alpha = 0.f, step_size = 0.f, sq_bc2 = 1.f;
+    if (mode == LQ_ADAM_KERAS) {
+        const float b1p = powf(b1, (float)step), b2p = powf(b2, (float)step);
+        alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    } else {
+        const double bc1 = 1.0 - pow(b1_d, (double)step), bc2 = 1.0 - pow(b2_d, (double)step);
+        step_size = (float)(lr_d / bc1);
+        sq_bc2 = (float)sqrt(bc2);
+    }
+    for (int64_t i = threadIdx.x; i < t.n; i += kBlock) {
+        const float g = t.ds[i];
+        float mi = t.m[i], vi = t.v[i], w = t.s[i];
+        mi = mi + (g - mi) * f0;
+        vi = vi + (g * g - vi) * f1;
+        if (mode == LQ_ADAM_KERAS) w = w - (mi * alpha) / (sqrtf(vi) + eps);
+        else w = w - step_size * (mi / (sqrtf(vi) / sq_bc2 + eps));
+        w = (w < t.min_value) ? t.min_value : w;
+        t.m[i] = mi;
+        t.v[i] = vi;
+        t.s[i] = w;
+    }
+}
+
+}  // namespace lq
+
+#endif

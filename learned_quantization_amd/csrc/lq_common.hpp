@@ -1,0 +1,72 @@
+// lq_common.hpp -- constants, kernel parameter block, accumulator types (overview: lq_kernels.hip)
+#ifndef LQ_COMMON_HPP_
+#define LQ_COMMON_HPP_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lq_hip.h"
+
+namespace lq {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr float kEpsF32 = 1.1920928955078125e-07f;   // np.finfo(np.float32).eps, custom_layers.py:11
+constexpr int64_t kNtBytes = 64ll << 20;             // tensors at least this large are streamed with nontemporal accesses
+
+// ------------------------------------------------------------------------------------------
+//  Parameters shared by every kernel (passed by value in the kernarg segment).
+// ------------------------------------------------------------------------------------------
+struct Params {
+    const float* P;
+    const float* s;
+    const float* dy;
+    float* out;          // primary dense output (out for K1/K4, dP for penalty backward)
+    void* q;             // optional integer view
+    int q_dtype;
+    float lam;
+    int tmode;           // 0: lambda < 4e-4 (tanh(d) == d), 1: lambda <= 0.25 (polynomial), 2: general (ocml tanhf)
+    const float* mb;     // per-group max(|P|/s)      (maxbin backward)
+    const uint32_t* ties;
+    const float* c_dev;  // upstream gradient, device scalar
+    float c_scale;
+    uint32_t* pa;        // partials, SoA
+    uint32_t* pb;
+    float* pc;
+    int64_t outer, G, inner;
+};
+
+// Per-group context, loaded once per row / column.
+struct Ctx {
+    float s;
+    float r;      // RN(1/s)
+    int fast;     // s is inside the window where the uniform-divisor division is exact
+    float k0;
+    float k1;
+    float lam_hi; // RN(lambda * 1.000001): a >= lam_hi*b  =>  RN(a/b) >= lambda for sure
+    int sure_ok;  // lam_hi*b cannot underflow for any b this row can produce (b >= min(s, eps_f32))
+};
+
+// Narrow accumulator (inside streaming kernels) and wide accumulator (finalize).
+template <typename TB, typename TC>
+struct AccT {
+    uint32_t a;
+    TB b;
+    TC c;
+};
+using Acc = AccT<uint32_t, float>;
+using AccW = AccT<double, double>;   // finalize: count and sum in f64 (counts are exact below 2^53)
+
+enum OpKind {
+    OP_FWD = 0,        // K1
+    OP_BWD = 1,        // K2
+    OP_FUSED = 2,      // K4
+    OP_MAXBIN_FWD = 3, // K5a
+    OP_MAXBIN_BWD = 4,
+    OP_DIFF_FWD = 5,   // K5b
+    OP_DIFF_BWD = 6,
+    OP_QONLY = 7,      // integer view only (callbacks / export)
+};
+
+}  // namespace lq
+
+#endif

@@ -1,18 +1,28 @@
 // lq_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels for the learned-quantization
-// hot path, and the C ABI of include/lq_hip.h on top of them.
+// hot path, and the C ABI of include/lq_hip.h on top of them.  One translation unit:
+//
+//   lq_common.hpp       constants, kernel parameter block, accumulator types
+//   lq_math.hpp         exact fp32 arithmetic: uniform-divisor division, in-window ratio division, |tanh|, vote
+//   lq_ops.hpp          per-operation traits (K1 fwd, K2 bwd, K4 fused, K5 penalties, integer view)
+//   lq_reduce.hpp       wave/block reductions (DPP for the standard accumulator, shuffles for custom merges)
+//   lq_traverse.hpp     traversal modes (row stream / row small / column) + finalize kernels
+//   lq_aux_kernels.hpp  scale-sized kernels (K5c, K6), integer statistics, device self-test
+//   lq_batch.hpp        device side of the multi-tensor batch
+//   this file           host side: traversal plan, launchers, the extern "C" entry points
 //
 // The path is elementwise + per-group reductions: HBM-bound, no MFMA.  Design rules
-// (cdna_hip_programming.md G2/G11/G12/G13, MI355X_MICROARCH.md HBM):
-//   * 16-byte-per-lane coalesced global loads/stores (float4) on every large tensor;
-//   * the per-group scale is wave/block-uniform in the streaming kernels (one scalar
-//     load, SGPR broadcast) -- the group index never costs per-element integer division;
-//   * reductions: DPP/shuffle inside the 64-lane wave -> LDS across the 4 waves of a
-//     block -> one partial per block in a workspace -> a finalize kernel.  No float
-//     atomics: every sum is taken in a fixed order, results are run-to-run bit-stable;
-//   * max|q| is reduced on the uint32 bit pattern of |q| (order-independent, exact,
-//     NaN-propagating like np.max);
-//   * the integers must match the reference bit for bit: IEEE-754 correctly rounded
-//     fp32 division followed by floor (never a reciprocal multiply), -ffp-contract=off,
+// (cdna_hip_programming.md G2/G11/G12/G13, MI355X_MICROARCH.md HBM), each settled by measurement on the
+// device (tools/membench.hip, tools/bench_shapes.py):
+//   * one 16-byte coalesced access per lane and stream (float4), nontemporal for tensors >= 64 MiB; blocks of
+//     512 threads for streaming-size tensors; loads issued before the per-group context is computed;
+//   * the per-group scale is block-uniform in the streaming kernels (one scalar load, SGPR broadcast) -- the
+//     group index never costs per-element integer division (3-D grid / loop-invariant lane->column maps);
+//   * reductions: DPP inside the 64-lane wave -> LDS across the block's waves -> one partial per block in a
+//     caller-provided workspace -> a finalize kernel.  No float atomics: every sum is taken in a fixed
+//     order, results are run-to-run bit-stable;
+//   * max|q| is reduced on the uint32 bit pattern of |q| (order-independent, exact);
+//   * the integers must match the reference bit for bit: IEEE-754 correctly rounded fp32 division followed
+//     by floor (never a reciprocal multiply; the fast forms are proven/validated exact), -ffp-contract=off,
 //     no fast-math.
 //
 // Reference semantics restated here (file:line relative to /root/reference):
@@ -32,1408 +42,9 @@
 
 #include "lq_hip.h"
 
+#include "lq_batch.hpp"
+
 namespace lq {
-
-constexpr int kBlock = 256;
-constexpr int kWavesPerBlock = kBlock / 64;
-constexpr float kEpsF32 = 1.1920928955078125e-07f;   // np.finfo(np.float32).eps, custom_layers.py:11
-constexpr int64_t kNtBytes = 64ll << 20;             // tensors at least this large are streamed with nontemporal accesses
-
-// ------------------------------------------------------------------------------------------
-//  Parameters shared by every kernel (passed by value in the kernarg segment).
-// ------------------------------------------------------------------------------------------
-struct Params {
-    const float* P;
-    const float* s;
-    const float* dy;
-    float* out;          // primary dense output (out for K1/K4, dP for penalty backward)
-    void* q;             // optional integer view
-    int q_dtype;
-    float lam;
-    int tmode;           // 0: lambda < 4e-4 (tanh(d) == d), 1: lambda <= 0.25 (polynomial), 2: general (ocml tanhf)
-    const float* mb;     // per-group max(|P|/s)      (maxbin backward)
-    const uint32_t* ties;
-    const float* c_dev;  // upstream gradient, device scalar
-    float c_scale;
-    uint32_t* pa;        // partials, SoA
-    uint32_t* pb;
-    float* pc;
-    int64_t outer, G, inner;
-};
-
-// Per-group context, loaded once per row / column.
-struct Ctx {
-    float s;
-    float r;      // RN(1/s)
-    int fast;     // s is inside the window where the uniform-divisor division is exact
-    float k0;
-    float k1;
-    float lam_hi; // RN(lambda * 1.000001): a >= lam_hi*b  =>  RN(a/b) >= lambda for sure
-    int sure_ok;  // lam_hi*b cannot underflow for any b this row can produce (b >= min(s, eps_f32))
-};
-
-// Narrow accumulator (inside streaming kernels) and wide accumulator (finalize).
-template <typename TB, typename TC>
-struct AccT {
-    uint32_t a;
-    TB b;
-    TC c;
-};
-using Acc = AccT<uint32_t, float>;
-using AccW = AccT<double, double>;   // finalize: count and sum in f64 (counts are exact below 2^53)
-
-enum OpKind {
-    OP_FWD = 0,        // K1
-    OP_BWD = 1,        // K2
-    OP_FUSED = 2,      // K4
-    OP_MAXBIN_FWD = 3, // K5a
-    OP_MAXBIN_BWD = 4,
-    OP_DIFF_FWD = 5,   // K5b
-    OP_DIFF_BWD = 6,
-    OP_QONLY = 7,      // integer view only (callbacks / export)
-};
-
-// ------------------------------------------------------------------------------------------
-//  x / s for a divisor that is uniform over the block: correctly rounded, ~8 VALU instead of the
-//  ~15-instruction v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence.
-//    r = RN(1/s);  q0 = RN(x r);  e0 = x - s q0 (exact, fma);  q1 = RN(q0 + e0 r);
-//    e1 = x - s q1 (exact);  t = RN(q1 + e1 r)
-//  By Markstein's theorem the last step rounds correctly when r is the correctly rounded
-//  reciprocal and q1 is within 1 ulp, for every s whose mantissa is not all ones.  The window
-//  (2^-40 <= s <= 2^40, 2^-80 <= |x| < 2^81) keeps every intermediate normal so that the
-//  residuals are exact; anything outside (zeros, denormals, Inf, NaN, huge, s <= 0) takes the IEEE
-//  `/`.  tests/tools/check_fast_div.c checks the sequence against `/` for all 2^23 mantissas of x
-//  per divisor; tests/test_gpu_parity.py checks the kernels bit for bit against the oracle.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void div_ctx(Ctx& c) {
-    const uint32_t sb = __float_as_uint(c.s);
-    const uint32_t ex = (sb >> 23) & 0xffu;
-    const bool ok = (sb >> 31) == 0u && ex >= 127u - 40u && ex <= 127u + 40u && (sb & 0x7fffffu) != 0x7fffffu;
-    c.r = 1.0f / c.s;
-    c.fast = ok ? 1 : 0;
-}
-
-__device__ __forceinline__ float div_by_uniform(float x, const Ctx& c) {
-    if (c.fast) {   // block/row-uniform
-        const uint32_t ex = (__float_as_uint(x) >> 23) & 0xffu;
-        if (__builtin_expect((ex - 47u) <= 160u, 1)) {
-            const float q0 = x * c.r;
-            const float e0 = __builtin_fmaf(-c.s, q0, x);
-            const float q1 = __builtin_fmaf(e0, c.r, q0);
-            const float e1 = __builtin_fmaf(-c.s, q1, x);
-            return __builtin_fmaf(e1, c.r, q1);
-        }
-        if (x == 0.0f) return x;   // (+-0) / s = +-0 for s > 0
-    }
-    return x / c.s;                // IEEE RN fp32 division (hipcc default: correctly rounded)
-}
-
-// |tanh(d)| for d = lambda - ratio, 0 < d <= lambda (or NaN).
-//   tmode 0 (lambda < 4e-4): tanh(d) == d to fp32 precision (d^2/3 < 2^-24) -- every published
-//           threshold (lambda <= 1e-8) is here;
-//   tmode 1 (lambda <= 0.25): odd minimax polynomial, < 1 ulp on [0, 0.25];
-//   tmode 2: ocml tanhf.
-template <int TM>
-__device__ __forceinline__ float abs_tanh_t(float d) {
-    const float a = fabsf(d);
-    if (TM == 0) return a;
-    if (TM == 1) {
-        const float z = a * a;
-        float p = 2.0800685256e-02f;
-        p = __builtin_fmaf(p, z, -5.3927052600e-02f);
-        p = __builtin_fmaf(p, z, 1.3333282305e-01f);
-        p = __builtin_fmaf(p, z, -3.3333333236e-01f);
-        return __builtin_fmaf(a * z, p, a);
-    }
-    return a < 4.0e-4f ? a : tanhf(a);
-}
-
-__device__ __forceinline__ float abs_tanh(float d, int tmode) {
-    if (tmode == 0) return abs_tanh_t<0>(d);
-    if (tmode == 1) return abs_tanh_t<1>(d);
-    return abs_tanh_t<2>(d);
-}
-
-__device__ __forceinline__ void fq_core(float x, const Ctx& c, float& q, float& o) {
-    const float t = div_by_uniform(x, c);   // custom_layers.py:56-58
-    q = floorf(t);                           // :59
-    o = q * c.s;                             // :60
-}
-
-__device__ __forceinline__ void nq_accumulate(float q, float o, float dy, float lam, int tmode, Acc& acc) {
-    const float nz = (o == 0.0f) ? kEpsF32 : o;        // :63
-    const float a = fabsf(dy), b = fabsf(nz);
-    acc.a = __float_as_uint(fmaxf(__uint_as_float(acc.a), fabsf(q)));   // :68 / :94
-    const float ratio = a / b;                         // :64
-    if (!(ratio >= lam)) {                             // :70 / :97 (NaN counts as "not above")
-        acc.b += 1u;
-        acc.c -= abs_tanh(lam - ratio, tmode);         // :84 / :110
-    }
-}
-
-// ---- float4 forms: branch-light.  One (rarely taken) branch for the division window, one for
-// "does any of the 4 elements need the exact ratio", everything else straight-line VALU.
-__device__ __forceinline__ float fast_div(float x, float s, float r) {
-    const float q0 = x * r;
-    const float e0 = __builtin_fmaf(-s, q0, x);
-    const float q1 = __builtin_fmaf(e0, r, q0);
-    const float e1 = __builtin_fmaf(-s, q1, x);
-    return __builtin_fmaf(e1, r, q1);
-}
-
-__device__ __forceinline__ void fq_core4(const float4& x, const Ctx& c, float4& q, float4& o) {
-    // window 2^-80 <= |x| < 2^81 for all four, via min3/max3 with |.| source modifiers.  fminf/fmaxf
-    // ignore a NaN operand, which is harmless: a NaN x gives a NaN quotient on the fast path too; an
-    // all-NaN group fails the comparison and takes the IEEE path.  Inf and 0 fail the window.
-    const float amax = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
-    const float amin = fminf(fminf(fabsf(x.x), fabsf(x.y)), fminf(fabsf(x.z), fabsf(x.w)));
-    float4 t;
-    if (__builtin_expect((c.fast != 0) & (amin >= 8.271806125530277e-25f) & (amax < 2.4178516392292583e+24f), 1)) {
-        t.x = fast_div(x.x, c.s, c.r);
-        t.y = fast_div(x.y, c.s, c.r);
-        t.z = fast_div(x.z, c.s, c.r);
-        t.w = fast_div(x.w, c.s, c.r);
-    } else {   // zeros, denormals, Inf, huge, or a divisor outside the window: IEEE division
-        t.x = x.x / c.s;
-        t.y = x.y / c.s;
-        t.z = x.z / c.s;
-        t.w = x.w / c.s;
-    }
-    q.x = floorf(t.x); q.y = floorf(t.y); q.z = floorf(t.z); q.w = floorf(t.w);
-    o.x = q.x * c.s; o.y = q.y * c.s; o.z = q.z * c.s; o.w = q.w * c.s;
-}
-
-__device__ __forceinline__ void vote_ctx(Ctx& c, float lam) {
-    c.lam_hi = lam * 1.000001f;
-    const float bmin = fminf(fabsf(c.s), kEpsF32);      // b = |q*s| >= |s| when q != 0, else eps (:63)
-    c.sure_ok = (lam == 0.0f || c.lam_hi * bmin >= 1.0e-30f) ? 1 : 0;
-}
-
-// exact vote of one element (IEEE ratio): custom_layers.py:64, :70/:97, :84/:110
-// ------------------------------------------------------------------------------------------
-//  a / b for per-element operands, bit-identical to the IEEE `/` inside a window.  hipcc expands `/` to
-//     d' = v_div_scale(b); n' = v_div_scale(a); r0 = v_rcp(d'); e = fma(-d',r0,1); r = fma(e,r0,r0);
-//     q0 = n'*r; e1 = fma(-d',q0,n'); q1 = fma(e1,r,q0); e2 = fma(-d',q1,n'); q = v_div_fmas(e2,r,q1); v_div_fixup
-//  For 2^-40 <= a,b <= 2^40 the two v_div_scale are identities (exponent difference < 96, no denormals),
-//  v_div_fmas is a plain fma and v_div_fixup changes nothing (no NaN/Inf/0 operands), so the SAME
-//  rcp + fma chain without them gives the same bits -- and, being plain fma/mul, is packed two-wide
-//  (v_pk_fma_f32) across the elements of a float4.  Verified on the device against `/` by
-//  lq_selftest_ratio_division (tests/test_gpu_parity.py) on 2^33 random in-window pairs.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float window_div(float a, float b) {
-    const float r0 = __builtin_amdgcn_rcpf(b);
-    const float e = __builtin_fmaf(-b, r0, 1.0f);
-    const float r = __builtin_fmaf(e, r0, r0);
-    const float q0 = a * r;
-    const float e1 = __builtin_fmaf(-b, q0, a);
-    const float q1 = __builtin_fmaf(e1, r, q0);
-    const float e2 = __builtin_fmaf(-b, q1, a);
-    return __builtin_fmaf(e2, r, q1);
-}
-constexpr float kWinLo = 9.094947017729282e-13f;   // 2^-40
-constexpr float kWinHi = 1.099511627776e+12f;      // 2^40
-
-// exact vote of one element given its IEEE ratio: custom_layers.py:70/:97, :84/:110
-template <int TM>
-__device__ __forceinline__ void vote_tally(float ratio, float lam, Acc& acc) {
-    const bool below = !(ratio >= lam);                  // NaN counts as "not above"
-    acc.b += below ? 1u : 0u;
-    const float t = abs_tanh_t<TM>(lam - ratio);
-    acc.c -= below ? t : 0.0f;
-}
-
-template <int TM>
-__device__ __forceinline__ void vote_cast(float a, float b, float lam, Acc& acc) {
-    vote_tally<TM>(a / b, lam, acc);                     // :64 (IEEE)
-}
-
-template <int TM>
-__device__ __forceinline__ void vote_cast4(const float4& dy, float b0, float b1, float b2, float b3, float lam, Acc& acc) {
-    const float a0 = fabsf(dy.x), a1 = fabsf(dy.y), a2 = fabsf(dy.z), a3 = fabsf(dy.w);
-    const float lo = fminf(fminf(fminf(a0, a1), fminf(a2, a3)), fminf(fminf(b0, b1), fminf(b2, b3)));
-    const float hi = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
-    // fminf/fmaxf skip a NaN operand: test every operand for NaN through one sum (NaN propagates through +)
-    const float nan_probe = (a0 + a1) + (a2 + a3) + ((b0 + b1) + (b2 + b3));
-    float r0, r1, r2, r3;
-    if ((lo >= kWinLo) & (hi <= kWinHi) & (nan_probe == nan_probe)) {
-        r0 = window_div(a0, b0);
-        r1 = window_div(a1, b1);
-        r2 = window_div(a2, b2);
-        r3 = window_div(a3, b3);
-    } else {
-        r0 = a0 / b0;
-        r1 = a1 / b1;
-        r2 = a2 / b2;
-        r3 = a3 / b3;
-    }
-    vote_tally<TM>(r0, lam, acc);
-    vote_tally<TM>(r1, lam, acc);
-    vote_tally<TM>(r2, lam, acc);
-    vote_tally<TM>(r3, lam, acc);
-}
-
-__device__ __forceinline__ void nq_accumulate4(const float4& q, const float4& o, const float4& dy, const Ctx& c, float lam,
-                                               int tmode, Acc& acc) {
-    // max|q| as a float max with |.| modifiers (q is integer-valued: exact).  A NaN q is ignored here, but
-    // then out is NaN -> ratio NaN -> the vote sum and ds are NaN anyway.
-    const float mq = fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w)));
-    acc.a = __float_as_uint(fmaxf(__uint_as_float(acc.a), mq));
-    const float b0 = (o.x == 0.0f) ? kEpsF32 : fabsf(o.x);   // :63
-    const float b1 = (o.y == 0.0f) ? kEpsF32 : fabsf(o.y);
-    const float b2 = (o.z == 0.0f) ? kEpsF32 : fabsf(o.z);
-    const float b3 = (o.w == 0.0f) ? kEpsF32 : fabsf(o.w);
-    // ratio >= lambda is certain when |dy| >= RN(lam_hi*b): a/b >= lambda(1+8e-7) > lambda and RN is monotonic.
-    // Such elements contribute nothing to the vote (:82/:108); only if some lane has an uncertain element
-    // are the four IEEE divisions done (a sure element then simply evaluates to "not below").
-    const bool all_sure = (c.sure_ok != 0) & (fabsf(dy.x) >= c.lam_hi * b0) & (fabsf(dy.y) >= c.lam_hi * b1) &
-                          (fabsf(dy.z) >= c.lam_hi * b2) & (fabsf(dy.w) >= c.lam_hi * b3);
-    if (!all_sure) {
-        if (tmode == 0) vote_cast4<0>(dy, b0, b1, b2, b3, lam, acc);        // kernel-uniform
-        else if (tmode == 1) vote_cast4<1>(dy, b0, b1, b2, b3, lam, acc);
-        else vote_cast4<2>(dy, b0, b1, b2, b3, lam, acc);
-    }
-}
-
-template <int Q>
-__device__ __forceinline__ void store_q_scalar(void* qp, int64_t i, float q) {
-    if (Q == LQ_Q_F32) {
-        reinterpret_cast<float*>(qp)[i] = q;
-    } else if (Q == LQ_Q_I32) {
-        reinterpret_cast<int32_t*>(qp)[i] = (q != q) ? 0 : (q >= 2147483648.0f ? INT32_MAX : (q <= -2147483648.0f ? INT32_MIN : (int32_t)q));
-    } else if (Q == LQ_Q_I8) {
-        // two's-complement wrap of the (finite) integer value: what a C cast chain float->int64->int8 gives
-        long long w = (q != q || fabsf(q) > 9.0e18f) ? 0ll : (long long)q;
-        reinterpret_cast<int8_t*>(qp)[i] = (int8_t)(uint8_t)(w & 0xff);
-    }
-}
-
-__device__ __forceinline__ void store_q(void* qp, int q_dtype, int64_t i, float q) {
-    switch (q_dtype) {
-        case LQ_Q_F32: store_q_scalar<LQ_Q_F32>(qp, i, q); break;
-        case LQ_Q_I32: store_q_scalar<LQ_Q_I32>(qp, i, q); break;
-        case LQ_Q_I8: store_q_scalar<LQ_Q_I8>(qp, i, q); break;
-        default: break;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-//  Op traits.  elem() consumes one element (x, dy) of group context c at flat index i, returns
-//  the value of the primary dense output (stored, vectorised, by the traversal when kStore)
-//  and folds into acc when kReduce.
-// ------------------------------------------------------------------------------------------
-template <int OP>
-struct OpT;
-
-struct OpBase {
-    static constexpr bool kStdMerge = true;   // merge is (max, add, add): DPP reduction applies
-    static constexpr bool kVec4 = false;      // op provides elem4()
-    static constexpr bool kDy = false;
-    static constexpr bool kStore = false;
-    static constexpr bool kReduce = false;
-    template <typename A>
-    __device__ static __forceinline__ A init() {
-        A a;
-        a.a = 0u;
-        a.b = 0;
-        a.c = 0;
-        return a;
-    }
-    template <typename A, typename B>
-    __device__ static __forceinline__ void merge(A& x, const B& y) {
-        x.a = y.a > x.a ? y.a : x.a;
-        x.b += y.b;
-        x.c += y.c;
-    }
-    __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) {
-        Ctx c;
-        c.s = p.s[g];
-        div_ctx(c);
-        c.k0 = 0.f;
-        c.k1 = 0.f;
-        vote_ctx(c, p.lam);
-        return c;
-    }
-};
-
-template <>
-struct OpT<OP_FWD> : OpBase {
-    static constexpr bool kStore = true;
-    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float, Acc&) {
-        float q, o;
-        fq_core(x, c, q, o);
-        if (p.q) store_q(p.q, p.q_dtype, i, q);
-        return o;
-    }
-    static constexpr bool kVec4 = true;
-    __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t i, const float4& x, const float4&, Acc&) {
-        float4 q, o;
-        fq_core4(x, c, q, o);
-        if (p.q) {
-            store_q(p.q, p.q_dtype, i + 0, q.x);
-            store_q(p.q, p.q_dtype, i + 1, q.y);
-            store_q(p.q, p.q_dtype, i + 2, q.z);
-            store_q(p.q, p.q_dtype, i + 3, q.w);
-        }
-        return o;
-    }
-};
-
-template <>
-struct OpT<OP_QONLY> : OpBase {
-    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float, Acc&) {
-        float q, o;
-        fq_core(x, c, q, o);
-        store_q(p.q, p.q_dtype, i, q);
-        return 0.f;
-    }
-};
-
-template <>
-struct OpT<OP_BWD> : OpBase {
-    static constexpr bool kDy = true;
-    static constexpr bool kReduce = true;
-    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t, float x, float dy, Acc& acc) {
-        float q, o;
-        fq_core(x, c, q, o);
-        nq_accumulate(q, o, dy, p.lam, p.tmode, acc);
-        return 0.f;
-    }
-    static constexpr bool kVec4 = true;
-    __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t, const float4& x, const float4& dy, Acc& acc) {
-        float4 q, o;
-        fq_core4(x, c, q, o);
-        nq_accumulate4(q, o, dy, c, p.lam, p.tmode, acc);
-        return o;
-    }
-};
-
-template <>
-struct OpT<OP_FUSED> : OpBase {
-    static constexpr bool kDy = true;
-    static constexpr bool kStore = true;
-    static constexpr bool kReduce = true;
-    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t, float x, float dy, Acc& acc) {
-        float q, o;
-        fq_core(x, c, q, o);
-        nq_accumulate(q, o, dy, p.lam, p.tmode, acc);
-        return o;
-    }
-    static constexpr bool kVec4 = true;
-    __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t, const float4& x, const float4& dy, Acc& acc) {
-        float4 q, o;
-        fq_core4(x, c, q, o);
-        nq_accumulate4(q, o, dy, c, p.lam, p.tmode, acc);
-        return o;
-    }
-};
-
-// K5a forward: a = bits(max |P|/s), b = number of elements attaining it.
-template <>
-struct OpT<OP_MAXBIN_FWD> : OpBase {
-    static constexpr bool kReduce = true;
-    static constexpr bool kStdMerge = false;
-    template <typename A, typename B>
-    __device__ static __forceinline__ void merge(A& x, const B& y) {
-        if (y.a > x.a) {
-            x.a = y.a;
-            x.b = y.b;
-        } else if (y.a == x.a) {
-            x.b += y.b;
-        }
-    }
-    __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc& acc) {
-        float t = fabsf(x) / c.s;                       // custom_loss_functions.py:92
-        uint32_t tb = __float_as_uint(fabsf(t));        // s > 0 in practice; |.| keeps the bit trick valid if not
-        if (tb > acc.a) {
-            acc.a = tb;
-            acc.b = 1u;
-        } else if (tb == acc.a) {
-            acc.b += 1u;
-        }
-        return 0.f;
-    }
-};
-
-// K5a backward: dP_i = (|P_i|/s == mb) ? sign(P_i) * coef / s : 0, coef = c / (G * ties)
-template <>
-struct OpT<OP_MAXBIN_BWD> : OpBase {
-    static constexpr bool kStore = true;
-    __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) {
-        Ctx c;
-        c.s = p.s[g];
-        c.r = 0.f;
-        c.fast = 0;
-        c.lam_hi = 0.f;
-        c.sure_ok = 0;
-        c.k0 = p.mb[g];
-        float up = p.c_dev[0] * p.c_scale;
-        c.k1 = (up / (float)p.G) / (float)p.ties[g];
-        return c;
-    }
-    __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc&) {
-        float t = fabsf(fabsf(x) / c.s);
-        float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-        return (t == c.k0) ? (c.k1 / c.s) * sgn : 0.f;
-    }
-};
-
-// K5b forward: c = sum |P - P/s|
-template <>
-struct OpT<OP_DIFF_FWD> : OpBase {
-    static constexpr bool kReduce = true;
-    __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc& acc) {
-        float pq = x / c.s;                             // custom_loss_functions.py:172
-        acc.c += fabsf(x - pq);                         // :175
-        return 0.f;
-    }
-};
-
-// K5b backward: gi = sign(u) * c/N ; dP = gi - gi/s ; ds[g] = sum gi * (P/s) / s
-template <>
-struct OpT<OP_DIFF_BWD> : OpBase {
-    static constexpr bool kStore = true;
-    static constexpr bool kReduce = true;
-    __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) {
-        Ctx c;
-        c.s = p.s[g];
-        c.r = 0.f;
-        c.fast = 0;
-        c.lam_hi = 0.f;
-        c.sure_ok = 0;
-        double n = (double)p.outer * (double)p.G * (double)p.inner;
-        c.k0 = (p.c_dev[0] * p.c_scale) / (float)n;
-        c.k1 = 0.f;
-        return c;
-    }
-    __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc& acc) {
-        float pq = x / c.s;
-        float u = x - pq;
-        float sgn = (u > 0.f) ? 1.f : ((u < 0.f) ? -1.f : 0.f);
-        float gi = sgn * c.k0;
-        acc.c += (gi * pq) / c.s;
-        return gi - gi / c.s;
-    }
-};
-
-// ------------------------------------------------------------------------------------------
-//  Reductions: wave butterfly (64 lanes) -> LDS across the block's waves.
-// ------------------------------------------------------------------------------------------
-template <class O, class A>
-__device__ __forceinline__ void wave_reduce(A& acc, int width = 64) {
-    for (int off = width >> 1; off > 0; off >>= 1) {
-        A o;
-        o.a = __shfl_xor(acc.a, off, 64);
-        o.b = __shfl_xor(acc.b, off, 64);
-        o.c = __shfl_xor(acc.c, off, 64);
-        O::merge(acc, o);
-    }
-}
-
-// Result valid in thread 0.  BS = block size (multiple of 64).
-template <class O, class A, int BS>
-__device__ __forceinline__ void block_reduce(A& acc) {
-    __shared__ A lds[BS / 64];
-    wave_reduce<O>(acc);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) lds[wid] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        A r = lds[0];
-#pragma unroll
-        for (int w = 1; w < BS / 64; ++w) O::merge(r, lds[w]);
-        acc = r;
-    }
-}
-
-__device__ __forceinline__ void write_partial(const Params& p, int64_t idx, const Acc& acc) {
-    p.pa[idx] = acc.a;
-    p.pb[idx] = acc.b;
-    p.pc[idx] = acc.c;
-}
-
-// ------------------------------------------------------------------------------------------
-//  DPP wave reduction for the standard accumulator (a: max, b: add, c: add) -- VALU only, no LDS
-//  crossbar traffic: quad_perm x2, row_half_mirror, row_mirror give every lane of a 16-lane row
-//  the row total; row_bcast15 / row_bcast31 carry it across rows; lane 63 ends with the total.
-//  The combination order is fixed, so float sums are run-to-run bit-stable.
-// ------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void dpp_step(Acc& acc) {
-    const uint32_t a = dpp_u32<CTRL, ROW_MASK>(0u, acc.a);
-    const uint32_t b = dpp_u32<CTRL, ROW_MASK>(0u, acc.b);
-    const float c = __uint_as_float(dpp_u32<CTRL, ROW_MASK>(0u, __float_as_uint(acc.c)));
-    acc.a = a > acc.a ? a : acc.a;
-    acc.b += b;
-    acc.c += c;
-}
-__device__ __forceinline__ void dpp_row_reduce(Acc& acc) {   // every lane of each 16-lane row <- row total
-    dpp_step<0xB1, 0xf>(acc);    // quad_perm [1,0,3,2]
-    dpp_step<0x4E, 0xf>(acc);    // quad_perm [2,3,0,1]
-    dpp_step<0x141, 0xf>(acc);   // row_half_mirror
-    dpp_step<0x140, 0xf>(acc);   // row_mirror
-}
-__device__ __forceinline__ void dpp_wave_reduce(Acc& acc) {  // lane 63 <- wave total
-    dpp_row_reduce(acc);
-    dpp_step<0x142, 0xa>(acc);   // row_bcast15 into rows 1 and 3
-    dpp_step<0x143, 0xc>(acc);   // row_bcast31 into rows 2 and 3
-}
-
-// Block reduction for the standard accumulator; result valid in thread 0.  BS multiple of 64, <= 1024.
-template <int BS>
-__device__ __forceinline__ void block_reduce_dpp(Acc& acc) {
-    constexpr int NW = BS / 64;
-    __shared__ uint32_t sa[NW], sb[NW];
-    __shared__ float sc[NW];
-    dpp_wave_reduce(acc);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 63) {
-        sa[wid] = acc.a;
-        sb[wid] = acc.b;
-        sc[wid] = acc.c;
-    }
-    __syncthreads();
-    if (wid == 0) {
-        Acc r;
-        r.a = lane < NW ? sa[lane] : 0u;
-        r.b = lane < NW ? sb[lane] : 0u;
-        r.c = lane < NW ? sc[lane] : 0.f;
-        dpp_row_reduce(r);       // NW <= 16: one row holds every wave's partial
-        acc = r;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-//  Traversal 1 -- "row stream": rows of length L >= 1024.  One block per (row, chunk) unit of
-//  BS*4 elements; every thread owns exactly ONE float4 of each stream (measured on MI355X,
-//  tools/membench.hip: this shape with nontemporal accesses streams 2 reads at 6.8 TB/s, read+write
-//  at 6.5 TB/s, 2 reads + write at 6.5 TB/s; multi-float4-per-thread loops and persistent blocks
-//  are 5-15 % slower).  The scale is block-uniform.  Grid is 3-D (chunk, g, outer) so that no integer
-//  division is needed; a 1-D grid with division is the fallback for huge G / outer.
-//  VEC = 4: float4 accesses (L % 4 == 0 or a single flat row; 16-B aligned bases).
-//  NT: nontemporal loads/stores (streamed-once tensors far larger than the caches).
-// ------------------------------------------------------------------------------------------
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-template <int NT>
-__device__ __forceinline__ float4 load4(const float* p) {
-    if (NT) {
-        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
-        return make_float4(v.x, v.y, v.z, v.w);
-    }
-    return *reinterpret_cast<const float4*>(p);
-}
-template <int NT>
-__device__ __forceinline__ void store4(float* p, const float4& v) {
-    if (NT) {
-        const v4f t = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
-    } else {
-        *reinterpret_cast<float4*>(p) = v;
-    }
-}
-
-template <int OP, int VEC, int BS, int NT, int U = 1>
-__device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int64_t nc, int64_t row, int64_t ck, int64_t g) {
-    using O = OpT<OP>;
-    constexpr int CH = BS * 4 * U;
-    const int64_t base = row * L + ck * (int64_t)CH;
-    const int64_t rem = L - ck * (int64_t)CH;
-    const int len = rem < (int64_t)CH ? (int)rem : CH;
-    Acc acc = O::template init<Acc>();
-
-    if (VEC == 4) {
-        const int len4 = len >> 2;
-        // Issue the streaming loads FIRST (they depend only on the kernel arguments and the block index);
-        // the per-group context (scale fetch, reciprocal, thresholds) is computed while they are in flight.
-        // Inactive lanes of a partial chunk re-read float4 0 of the chunk instead of branching.
-        // A chunk with fewer than 4 elements (len4 == 0; only the last chunk of a flat row, so ck > 0)
-        // reads the float4 just before it: always in bounds, never used.
-        // U = 2 (two float4 per thread and stream) is used when lambda >= 4e-4: every element then takes the
-        // exact-ratio + tanh branch, a wave's compute phase triples, and one float4 per thread no longer keeps
-        // enough bytes in flight per wave-lifetime to stay HBM-bound.
-        int64_t i[U];
-        float4 x[U], d[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = u * BS + (int)threadIdx.x;
-            i[u] = base + (int64_t)(j < len4 ? j : 0) * 4;
-            const int64_t il = len4 > 0 ? i[u] : base - 4;
-            x[u] = load4<NT>(p.P + il);
-            d[u] = x[u];
-            if (O::kDy) d[u] = load4<NT>(p.dy + il);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the scale fetch + reciprocal below
-        const Ctx ctx = O::ctx(p, g);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = u * BS + (int)threadIdx.x;
-            if (j < len4) {
-                float4 r;
-                if constexpr (O::kVec4) {
-                    r = O::elem4(p, ctx, i[u], x[u], d[u], acc);
-                } else {
-                    r.x = O::elem(p, ctx, i[u] + 0, x[u].x, O::kDy ? d[u].x : 0.f, acc);
-                    r.y = O::elem(p, ctx, i[u] + 1, x[u].y, O::kDy ? d[u].y : 0.f, acc);
-                    r.z = O::elem(p, ctx, i[u] + 2, x[u].z, O::kDy ? d[u].z : 0.f, acc);
-                    r.w = O::elem(p, ctx, i[u] + 3, x[u].w, O::kDy ? d[u].w : 0.f, acc);
-                }
-                if (O::kStore) store4<NT>(p.out + i[u], r);
-            }
-        }
-        // ragged scalar tail: only a single flat row (G == 1) can have len % 4 != 0 on the vector path
-        const int tail = len & 3;
-        if ((int)threadIdx.x < tail) {
-            const int64_t i = base + (int64_t)len4 * 4 + threadIdx.x;
-            float r = O::elem(p, ctx, i, p.P[i], O::kDy ? p.dy[i] : 0.f, acc);
-            if (O::kStore) p.out[i] = r;
-        }
-    } else {
-        float x[4 * U], d[4 * U];
-#pragma unroll
-        for (int u = 0; u < 4 * U; ++u) {
-            const int j = u * BS + (int)threadIdx.x;
-            const int jc = j < len ? j : len - 1;      // clamp instead of predicate: the loads stay in flight together
-            x[u] = p.P[base + jc];
-            d[u] = O::kDy ? p.dy[base + jc] : 0.f;
-        }
-        const Ctx ctx = O::ctx(p, g);
-#pragma unroll
-        for (int u = 0; u < 4 * U; ++u) {
-            const int j = u * BS + (int)threadIdx.x;
-            if (j < len) {
-                float r = O::elem(p, ctx, base + j, x[u], d[u], acc);
-                if (O::kStore) p.out[base + j] = r;
-            }
-        }
-    }
-    if (O::kReduce) {
-        if constexpr (O::kStdMerge) {
-            block_reduce_dpp<BS>(acc);
-        } else {
-            block_reduce<O, Acc, BS>(acc);
-        }
-        if (threadIdx.x == 0) write_partial(p, row * nc + ck, acc);
-    }
-}
-
-template <int OP, int VEC, int BS, int NT, int U = 1>
-__global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params p, int64_t L, int64_t nc, int grid3d) {
-    int64_t row, ck, g;
-    if (grid3d) {
-        ck = blockIdx.x;
-        g = blockIdx.y;
-        row = (int64_t)blockIdx.z * p.G + g;
-    } else {
-        const int64_t unit = blockIdx.x;
-        row = unit / nc;
-        ck = unit - row * nc;
-        g = row % p.G;
-    }
-    row_stream_body<OP, VEC, BS, NT, U>(p, L, nc, row, ck, g);
-}
-
-// ------------------------------------------------------------------------------------------
-//  Traversal 2 -- "row small": rows of length L < 1024.  A team of 2^lpr_log2 lanes (<= 64,
-//  inside one wave) owns a row; 256 >> lpr_log2 rows per block; one partial per row.
-// ------------------------------------------------------------------------------------------
-template <int OP, int VEC>
-__device__ __forceinline__ void row_small_body(const Params& p, int64_t R, int L, int lpr_log2, int64_t blk) {
-    using O = OpT<OP>;
-    const int lpr = 1 << lpr_log2;
-    const int team = (int)threadIdx.x >> lpr_log2;
-    const int lane = (int)threadIdx.x & (lpr - 1);
-    const int64_t row = blk * (kBlock >> lpr_log2) + team;
-    const bool valid = row < R;
-    Acc acc = O::template init<Acc>();
-    if (valid) {
-        const Ctx ctx = O::ctx(p, row % p.G);
-        const int64_t base = row * (int64_t)L;
-        if (VEC == 4) {   // L % 4 == 0 and 16-B aligned bases: every row starts on a float4 boundary
-            const int L4 = L >> 2;
-#pragma unroll 2
-            for (int j = lane; j < L4; j += lpr) {
-                const int64_t i = base + (int64_t)j * 4;
-                const float4 x = *reinterpret_cast<const float4*>(p.P + i);
-                float4 d = x;
-                if (O::kDy) d = *reinterpret_cast<const float4*>(p.dy + i);
-                float4 r;
-                if constexpr (O::kVec4) {
-                    r = O::elem4(p, ctx, i, x, d, acc);
-                } else {
-                    r.x = O::elem(p, ctx, i + 0, x.x, O::kDy ? d.x : 0.f, acc);
-                    r.y = O::elem(p, ctx, i + 1, x.y, O::kDy ? d.y : 0.f, acc);
-                    r.z = O::elem(p, ctx, i + 2, x.z, O::kDy ? d.z : 0.f, acc);
-                    r.w = O::elem(p, ctx, i + 3, x.w, O::kDy ? d.w : 0.f, acc);
-                }
-                if (O::kStore) *reinterpret_cast<float4*>(p.out + i) = r;
-            }
-        } else {
-#pragma unroll 4
-            for (int j = lane; j < L; j += lpr) {
-                const float x = p.P[base + j];
-                const float d = O::kDy ? p.dy[base + j] : 0.f;
-                float r = O::elem(p, ctx, base + j, x, d, acc);
-                if (O::kStore) p.out[base + j] = r;
-            }
-        }
-    }
-    if (O::kReduce) {
-        wave_reduce<O>(acc, lpr);   // all 64 lanes execute the shuffles; teams never mix (xor < lpr)
-        if (valid && lane == 0) write_partial(p, row, acc);
-    }
-}
-
-template <int OP, int VEC>
-__global__ __launch_bounds__(kBlock) void k_row_small(Params p, int64_t R, int L, int lpr_log2) {
-    row_small_body<OP, VEC>(p, R, L, lpr_log2, (int64_t)blockIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------
-//  Traversal 3 -- "column": inner < 16 and outer > 1 (column-wise Dense, NHWC per-channel activations).
-//  The tensor is a matrix [outer][C], C = G*inner, the group changes along the contiguous axis.
-//  A block of 4 waves owns a tile of RB rows x (64*VW) columns; a lane keeps VW fixed columns (VW = 4:
-//  one float4 per row, when C % 4 == 0 and the bases are 16-B aligned), so its scales and accumulators
-//  are loop-invariant; wave w walks rows w, w+4, ...; the 4 waves' accumulators meet in LDS and one
-//  partial per (row-block, column) goes to the workspace.  For C <= 64 a whole wave would cover more
-//  than one row: there a wave scans floor(64/C) complete rows per load ("periodic" form, lane -> column
-//  lane % C), which keeps 60-64 of the 64 lanes busy for any C.
-//  (The first version -- one thread per column walking a slice of rows, 4-B loads, no tiling -- reached
-//  1.7 TB/s on a 6144 x 6144 column-wise matrix and 0.25 TB/s on NHWC C = 3.)
-// ------------------------------------------------------------------------------------------
-constexpr int kColUnroll = 4;
-
-template <class O>
-__device__ __forceinline__ void col_cross_wave(Acc* lds, const Acc& mine, int slot, int slots) {
-    lds[(threadIdx.x >> 6) * slots + slot] = mine;
-}
-
-template <int OP, int VW, int NT>
-__device__ __forceinline__ void col_tile_body(const Params& p, int64_t C, int64_t RB, int64_t bx, int64_t by) {
-    using O = OpT<OP>;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t col0 = (bx * 64 + lane) * VW;
-    const bool active = col0 < C;          // VW == 4 implies C % 4 == 0: a float4 never straddles a row end
-    Ctx ctx[VW];
-    Acc acc[VW];
-#pragma unroll
-    for (int k = 0; k < VW; ++k) {
-        acc[k] = O::template init<Acc>();
-        ctx[k] = O::ctx(p, active ? (col0 + k) / p.inner : 0);
-    }
-    const int64_t r0 = by * RB;
-    const int64_t r1 = (r0 + RB < p.outer) ? r0 + RB : p.outer;
-    if (active) {
-        for (int64_t r = r0 + w; r < r1; r += 4 * kColUnroll) {
-            float x[kColUnroll][VW], d[kColUnroll][VW];
-#pragma unroll
-            for (int u = 0; u < kColUnroll; ++u) {
-                const int64_t rr = (r + 4 * u < r1) ? r + 4 * u : r1 - 1;     // clamp: loads stay unconditional
-                const int64_t i = rr * C + col0;
-                if (VW == 4) {
-                    const float4 v = load4<NT>(p.P + i);
-                    x[u][0] = v.x; x[u][1 % VW] = v.y; x[u][2 % VW] = v.z; x[u][3 % VW] = v.w;
-                    if (O::kDy) {
-                        const float4 e = load4<NT>(p.dy + i);
-                        d[u][0] = e.x; d[u][1 % VW] = e.y; d[u][2 % VW] = e.z; d[u][3 % VW] = e.w;
-                    }
-                } else {
-                    x[u][0] = p.P[i];
-                    if (O::kDy) d[u][0] = p.dy[i];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < kColUnroll; ++u) {
-                if (r + 4 * u < r1) {
-                    const int64_t i = (r + 4 * u) * C + col0;
-                    float o[VW];
-#pragma unroll
-                    for (int k = 0; k < VW; ++k) o[k] = O::elem(p, ctx[k], i + k, x[u][k], O::kDy ? d[u][k] : 0.f, acc[k]);
-                    if (O::kStore) {
-                        if (VW == 4) store4<NT>(p.out + i, make_float4(o[0], o[1 % VW], o[2 % VW], o[3 % VW]));
-                        else p.out[i] = o[0];
-                    }
-                }
-            }
-        }
-    }
-    if (O::kReduce) {
-        __shared__ Acc lds[4 * 64 * VW];
-#pragma unroll
-        for (int k = 0; k < VW; ++k) lds[w * (64 * VW) + lane * VW + k] = acc[k];
-        __syncthreads();
-        if (w == 0 && active) {
-#pragma unroll
-            for (int k = 0; k < VW; ++k) {
-                Acc r = lds[lane * VW + k];
-#pragma unroll
-                for (int ww = 1; ww < 4; ++ww) O::merge(r, lds[ww * (64 * VW) + lane * VW + k]);   // fixed wave order
-                write_partial(p, by * C + col0 + k, r);
-            }
-        }
-    }
-}
-
-// C <= 64: lane -> (row rl = lane / C, column c = lane % C); a wave reads k = 64 / C whole rows per load.
-template <int OP>
-__device__ __forceinline__ void col_small_body(const Params& p, int C, int64_t RB, int64_t by) {
-    using O = OpT<OP>;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int k = 64 / C;
-    const bool active = lane < k * C;
-    const int rl = lane / C, c = lane - rl * C;
-    const Ctx ctx = O::ctx(p, active ? c / p.inner : 0);
-    Acc acc = O::template init<Acc>();
-    const int64_t r0 = by * RB;
-    const int64_t r1 = (r0 + RB < p.outer) ? r0 + RB : p.outer;
-    if (active) {
-        for (int64_t r = r0 + (int64_t)w * k + rl; r < r1; r += (int64_t)4 * k * kColUnroll) {
-            float x[kColUnroll], d[kColUnroll];
-#pragma unroll
-            for (int u = 0; u < kColUnroll; ++u) {
-                const int64_t rq = r + (int64_t)4 * k * u;
-                const int64_t rr = rq < r1 ? rq : r1 - 1;
-                x[u] = p.P[rr * C + c];
-                d[u] = O::kDy ? p.dy[rr * C + c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < kColUnroll; ++u) {
-                const int64_t rq = r + (int64_t)4 * k * u;
-                if (rq < r1) {
-                    const int64_t i = rq * C + c;
-                    const float o = O::elem(p, ctx, i, x[u], d[u], acc);
-                    if (O::kStore) p.out[i] = o;
-                }
-            }
-        }
-    }
-    if (O::kReduce) {
-        __shared__ Acc lds[4 * 64];
-        lds[threadIdx.x] = acc;
-        __syncthreads();
-        if ((int)threadIdx.x < C) {
-            Acc r = O::template init<Acc>();
-            for (int ww = 0; ww < 4; ++ww)
-                for (int q = 0; q < k; ++q) O::merge(r, lds[ww * 64 + q * C + (int)threadIdx.x]);      // fixed order
-            write_partial(p, by * C + threadIdx.x, r);
-        }
-    }
-}
-
-// variant: 0 = periodic (C <= 64), 1 = tile with scalar columns, 4 = tile with float4 (4 columns per lane),
-// 5 = float4 tile with nontemporal accesses (tensors >= 64 MiB)
-template <int OP>
-__device__ __forceinline__ void col_body(const Params& p, int64_t C, int64_t RB, int64_t nbx, int variant, int64_t b) {
-    if (variant == 0) {
-        col_small_body<OP>(p, (int)C, RB, b);
-    } else {
-        const int64_t by = b / nbx, bx = b - by * nbx;
-        if (variant == 5) col_tile_body<OP, 4, 1>(p, C, RB, bx, by);
-        else if (variant == 4) col_tile_body<OP, 4, 0>(p, C, RB, bx, by);
-        else col_tile_body<OP, 1, 0>(p, C, RB, bx, by);
-    }
-}
-
-template <int OP>
-__global__ __launch_bounds__(kBlock) void k_col(Params p, int64_t C, int64_t RB, int64_t nbx, int variant) {
-    col_body<OP>(p, C, RB, nbx, variant, (int64_t)blockIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------
-//  Finalize: merge the partials of each group in a fixed order (wide accumulator) and emit.
-//  Partial index of group g:  g*gstride + i1*stride1 + i2 ,  i1 < n1, i2 < n2.
-// ------------------------------------------------------------------------------------------
-struct FinGeom {
-    int64_t groups;
-    int64_t gstride, n1, stride1, n2;
-    double count;        // elements per group (outer * inner), or numel for a global reduction
-    float* o0;           // op-specific outputs
-    float* o1;
-    uint32_t* o2;
-};
-
-template <int OP>
-struct FinT;
-
-template <>
-struct FinT<OP_BWD> {
-    __device__ static void emit(const Params& p, const FinGeom& f, int64_t g, const AccW& a) {
-        const float maxq = __uint_as_float(a.a);
-        float mean;
-        if (a.b == 0.0) {
-            mean = -1.0f * fabsf(tanhf(p.lam));                 // custom_layers.py:79 / :105
-        } else {
-            mean = (float)(a.c / f.count);                      // :87 / :113
-        }
-        f.o0[g] = mean * maxq;                                  // :116
-        if (f.o1) {
-            f.o1[g] = maxq;
-            f.o1[f.groups + g] = mean;
-            f.o1[2 * f.groups + g] = (float)a.b;
-        }
-    }
-};
-template <>
-struct FinT<OP_FUSED> : FinT<OP_BWD> {};
-
-template <>
-struct FinT<OP_MAXBIN_FWD> {
-    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
-        f.o0[g] = __uint_as_float(a.a);
-        f.o2[g] = (uint32_t)(a.b > 4294967295.0 ? 4294967295.0 : a.b);
-    }
-};
-
-template <>
-struct FinT<OP_DIFF_FWD> {
-    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
-        f.o0[g] = (float)(a.c / f.count);                       // custom_loss_functions.py:175 reduce_mean
-    }
-};
-
-template <>
-struct FinT<OP_DIFF_BWD> {
-    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
-        f.o0[g] = (float)a.c;
-    }
-};
-
-template <class O>
-__device__ __forceinline__ AccW load_partial(const Params& p, int64_t idx) {
-    AccW w;
-    w.a = p.pa[idx];
-    w.b = (double)p.pb[idx];
-    w.c = (double)p.pc[idx];
-    return w;
-}
-
-// DPP reduction of the wide standard accumulator (max, add, add); same lane pattern as dpp_wave_reduce.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const unsigned long long u = __double_as_longlong(v);
-    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)u);
-    const uint32_t hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(u >> 32));
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void dpp_step_w(AccW& acc) {
-    const uint32_t a = dpp_u32<CTRL, ROW_MASK>(0u, acc.a);
-    const double b = dpp_f64<CTRL, ROW_MASK>(acc.b);
-    const double c = dpp_f64<CTRL, ROW_MASK>(acc.c);
-    acc.a = a > acc.a ? a : acc.a;
-    acc.b += b;
-    acc.c += c;
-}
-__device__ __forceinline__ void dpp_row_reduce_w(AccW& acc) {
-    dpp_step_w<0xB1, 0xf>(acc);
-    dpp_step_w<0x4E, 0xf>(acc);
-    dpp_step_w<0x141, 0xf>(acc);
-    dpp_step_w<0x140, 0xf>(acc);
-}
-
-// One block of BS threads per group.  Index arithmetic is 32-bit whenever the partial count allows (a 64-bit
-// division per loaded partial used to dominate this kernel).
-template <int OP, int BS>
-__device__ __forceinline__ void finalize_block_body(const Params& p, const FinGeom& f, int64_t g) {
-    using O = OpT<OP>;
-    const int64_t n = f.n1 * f.n2;
-    const int64_t gbase = g * f.gstride;
-    AccW acc = O::template init<AccW>();
-    if (n < 0x7fffffffll) {
-        const uint32_t n32 = (uint32_t)n, n2 = (uint32_t)f.n2;
-        for (uint32_t k = threadIdx.x; k < n32; k += BS) {
-            const uint32_t i1 = k / n2, i2 = k - i1 * n2;
-            O::merge(acc, load_partial<O>(p, gbase + (int64_t)i1 * f.stride1 + i2));
-        }
-    } else {
-        for (int64_t k = threadIdx.x; k < n; k += BS) {
-            const int64_t i1 = k / f.n2, i2 = k - i1 * f.n2;
-            O::merge(acc, load_partial<O>(p, gbase + i1 * f.stride1 + i2));
-        }
-    }
-    if constexpr (O::kStdMerge) {
-        constexpr int NW = BS / 64;
-        __shared__ uint32_t sa[NW];
-        __shared__ double sb[NW], sc[NW];
-        dpp_row_reduce_w(acc);
-        dpp_step_w<0x142, 0xa>(acc);
-        dpp_step_w<0x143, 0xc>(acc);
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        if (NW > 1) {
-            if (lane == 63) {
-                sa[wid] = acc.a;
-                sb[wid] = acc.b;
-                sc[wid] = acc.c;
-            }
-            __syncthreads();
-            if (wid == 0) {
-                AccW r;
-                r.a = lane < NW ? sa[lane] : 0u;
-                r.b = lane < NW ? sb[lane] : 0.0;
-                r.c = lane < NW ? sc[lane] : 0.0;
-                dpp_row_reduce_w(r);
-                if (lane == 0) FinT<OP>::emit(p, f, g, r);
-            }
-        } else if (lane == 63) {
-            FinT<OP>::emit(p, f, g, acc);
-        }
-    } else {
-        block_reduce<O, AccW, BS>(acc);
-        if (threadIdx.x == 0) FinT<OP>::emit(p, f, g, acc);
-    }
-}
-
-template <int OP, int BS>
-__global__ __launch_bounds__(BS) void k_finalize_block(Params p, FinGeom f) {
-    finalize_block_body<OP, BS>(p, f, (int64_t)blockIdx.x);
-}
-
-// One thread per group (few partials per group, possibly very many groups).
-template <int OP>
-__global__ __launch_bounds__(kBlock) void k_finalize_thread(Params p, FinGeom f) {
-    using O = OpT<OP>;
-    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= f.groups) return;
-    AccW acc = O::template init<AccW>();
-    for (int64_t i1 = 0; i1 < f.n1; ++i1)
-        for (int64_t i2 = 0; i2 < f.n2; ++i2) O::merge(acc, load_partial<O>(p, g * f.gstride + i1 * f.stride1 + i2));
-    FinT<OP>::emit(p, f, g, acc);
-}
-
-// ------------------------------------------------------------------------------------------
-//  Small vector kernels (scale-sized data).
-// ------------------------------------------------------------------------------------------
-// mode 0: out = mean(v[0..n))      mode 1: out = mean(1 / where(v==0, eps, v))
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_vec_mean(const float* v, int64_t n, float* out) {
-    double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += kBlock) {
-        float x = v[i];
-        if (MODE == 1) {
-            float nz = (x == 0.0f) ? kEpsF32 : x;     // custom_loss_functions.py:252
-            x = 1.0f / nz;                            // :255
-        }
-        acc += (double)x;
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    __shared__ double lds[kWavesPerBlock];
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = lds[0];
-        for (int w = 1; w < kWavesPerBlock; ++w) t += lds[w];
-        out[0] = (float)(t / (double)n);
-    }
-}
-
-__global__ void k_maxbin_ds(const float* s, const float* mb, const float* c_dev, float c_scale, float* ds, int64_t G) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    const float up = c_dev[0] * c_scale;
-    // sum over ties of -(g_i) * t / s with g_i = up/(G*ties): = -(up/G) * mb / s
-    ds[g] = -((up / (float)G) * mb[g]) / s[g];
-}
-
-__global__ void k_inverse_bwd(const float* s, const float* c_dev, float c_scale, float* ds, int64_t G) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    const float up = c_dev[0] * c_scale;
-    const float sg = s[g];
-    // d/ds mean(1/s) = -1/(G s^2); tf.where routes no gradient into s where s == 0
-    ds[g] = (sg == 0.0f) ? 0.0f : -((up / (float)G) / sg) / sg;
-}
-
-// f0..f3 are host-computed factors (python-double arithmetic rounded to fp32, as Keras / torch do):
-//   keras: f0 = 1-b1, f1 = 1-b2, f2 = alpha = lr*sqrt(1-b2^t)/(1-b1^t), f3 = eps
-//   torch: f0 = 1-b1, f1 = 1-b2, f2 = lr/(1-b1^t), f3 = eps, f4 = sqrt(1-b2^t)
-__global__ void k_adam(float* s, const float* ds, float* m, float* v, int64_t n, float f0, float f1, float f2, float f3,
-                       float f4, float min_value, int mode) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float g = ds[i];
-    float mi = m[i], vi = v[i], w = s[i];
-    mi = mi + (g - mi) * f0;
-    vi = vi + (g * g - vi) * f1;
-    if (mode == LQ_ADAM_KERAS) {
-        w = w - (mi * f2) / (sqrtf(vi) + f3);
-    } else {
-        const float denom = sqrtf(vi) / f4 + f3;
-        w = w - f2 * (mi / denom);
-    }
-    w = (w < min_value) ? min_value : w;   // MinValueConstraint: max(w, min_value); NaN stays NaN
-    m[i] = mi;
-    v[i] = vi;
-    s[i] = w;
-}
-
-// Same update, with the 1-based step read from device memory (hipGraph-capturable: nothing about the
-// step is baked into the launch).  Keras mode forms beta^t in fp32 like tf.pow; torch mode in fp64.
-__global__ void k_adam_dev(float* s, const float* ds, float* m, float* v, int64_t n, float lr, float b1, float b2, double lr_d,
-                           double b1_d, double b2_d, float f0, float f1, float eps, const int64_t* step_dev, float min_value,
-                           int mode) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t step = step_dev[0];
-    const float g = ds[i];
-    float mi = m[i], vi = v[i], w = s[i];
-    mi = mi + (g - mi) * f0;
-    vi = vi + (g * g - vi) * f1;
-    if (mode == LQ_ADAM_KERAS) {
-        const float b1p = powf(b1, (float)step), b2p = powf(b2, (float)step);
-        const float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
-        w = w - (mi * alpha) / (sqrtf(vi) + eps);
-    } else {
-        const double bc1 = 1.0 - pow(b1_d, (double)step), bc2 = 1.0 - pow(b2_d, (double)step);
-        const float step_size = (float)(lr_d / bc1);
-        const float denom = sqrtf(vi) / (float)sqrt(bc2) + eps;
-        w = w - step_size * (mi / denom);
-    }
-    w = (w < min_value) ? min_value : w;
-    m[i] = mi;
-    v[i] = vi;
-    s[i] = w;
-}
-
-__global__ void k_min_project(float* w, int64_t n, float min_value) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = w[i];
-    w[i] = (x < min_value) ? min_value : x;   // tf.maximum(w, min_value); NaN propagates
-}
-
-// result[a, b] = max over the middle axis of |floor(P/s)| for a tensor viewed (pre, n_axis, post)
-__global__ void k_q_absmax_axis(const float* P, const float* s, float* result, int64_t pre, int64_t n_axis, int64_t post,
-                                int64_t G, int64_t inner) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= pre * post) return;
-    const int64_t a = t / post, b = t - a * post;
-    uint32_t best = 0u;
-    for (int64_t k = 0; k < n_axis; ++k) {
-        const int64_t i = (a * n_axis + k) * post + b;
-        Ctx c;
-        c.s = s[(i / inner) % G];
-        c.r = 0.f;
-        c.fast = 0;
-        c.lam_hi = 0.f;
-        c.sure_ok = 0;
-        c.k0 = c.k1 = 0.f;
-        float q, o;
-        fq_core(P[i], c, q, o);
-        const uint32_t bits = __float_as_uint(fabsf(q));
-        best = bits > best ? bits : best;
-    }
-    result[t] = __uint_as_float(best);
-}
-
-// ------------------------------------------------------------------------------------------
-//  Integer-view statistics for the tracking callbacks (custom_callbacks.py:85-96, 131-207): range and
-//  histogram of q = floor(P/s).  Integer atomics only -> exact and independent of arrival order.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool q_as_int(float x, float sg, int32_t& qi) {
-    const float q = floorf(x / sg);
-    if (!(fabsf(q) < 2147483520.0f)) return false;   // NaN / Inf / beyond int32: not counted
-    qi = (int32_t)q;
-    return true;
-}
-
-__global__ __launch_bounds__(kBlock) void k_q_minmax(const float* __restrict__ P, const float* __restrict__ s, int32_t* minmax,
-                                                     int64_t n, int64_t G, int64_t inner) {
-    int32_t lo = INT32_MAX, hi = INT32_MIN;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        int32_t qi;
-        if (q_as_int(P[i], s[(i / inner) % G], qi)) {
-            lo = qi < lo ? qi : lo;
-            hi = qi > hi ? qi : hi;
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const int32_t l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (lo != INT32_MAX) atomicMin(&minmax[0], lo);
-        if (hi != INT32_MIN) atomicMax(&minmax[1], hi);
-    }
-}
-
-constexpr int kHistLds = 4096;   // bins privatised in LDS per block (the trained models use a few dozen integers)
-
-__global__ __launch_bounds__(kBlock) void k_q_histogram(const float* __restrict__ P, const float* __restrict__ s, int32_t qmin,
-                                                        int64_t nbins, uint32_t* bins, int64_t n, int64_t G, int64_t inner) {
-    __shared__ uint32_t lh[kHistLds];
-    const bool priv = nbins <= kHistLds;
-    if (priv) {
-        for (int b = threadIdx.x; b < (int)nbins; b += kBlock) lh[b] = 0u;
-        __syncthreads();
-    }
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        int32_t qi;
-        if (!q_as_int(P[i], s[(i / inner) % G], qi)) continue;
-        const int64_t b = (int64_t)qi - (int64_t)qmin;
-        if (b < 0 || b >= nbins) continue;
-        if (priv) atomicAdd(&lh[b], 1u);
-        else atomicAdd(&bins[b], 1u);
-    }
-    if (priv) {
-        __syncthreads();
-        for (int b = threadIdx.x; b < (int)nbins; b += kBlock) {
-            const uint32_t c = lh[b];
-            if (c) atomicAdd(&bins[b], c);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-//  Device self-test of window_div against the IEEE division (random in-window operand pairs).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_selftest_ratio_div(uint64_t seed, uint32_t per_thread, unsigned long long* mismatches) {
-    uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * ((uint64_t)blockIdx.x * kBlock + threadIdx.x + 1));
-    unsigned long long bad = 0;
-    for (uint32_t k = 0; k < per_thread; ++k) {
-        x ^= x << 13;
-        x ^= x >> 7;
-        x ^= x << 17;
-        // exponents 87..167 (2^-40 .. 2^40), random mantissas; the top of the window is clamped to exactly 2^40
-        uint32_t ea = 87u + (uint32_t)((x >> 8) % 81u), eb = 87u + (uint32_t)((x >> 24) % 81u);
-        uint32_t ma = (uint32_t)(x >> 40) & 0x7fffffu, mb = (uint32_t)(x * 0x2545F4914F6CDD1Dull >> 41) & 0x7fffffu;
-        if (ea == 167u) ma = 0u;
-        if (eb == 167u) mb = 0u;
-        const float a = __uint_as_float((ea << 23) | ma), b = __uint_as_float((eb << 23) | mb);
-        const float want = a / b;
-        const float got = window_div(a, b);
-        bad += (__float_as_uint(want) != __float_as_uint(got)) ? 1ull : 0ull;
-    }
-    if (bad) atomicAdd(mismatches, bad);
-}
-
-// ------------------------------------------------------------------------------------------
-//  Multi-tensor batch (SURVEY f-4): the 4 / 12 / 40 weight-sized tensors a training step fake-quantises
-//  are latency-bound one by one (each launch costs more than its work).  A batch is a device-resident
-//  table of tasks; ONE launch covers every tensor's traversal (each 256-thread block finds its task by
-//  binary search over the block prefix) and ONE launch finalizes every group of every tensor.  The per-
-//  tensor code is exactly the single-tensor traversal bodies above, so results are bit-identical.
-// ------------------------------------------------------------------------------------------
-struct Task {
-    Params p;                 // pa/pb/pc are rebound to the batch workspace inside the kernel
-    float* ds;                // scale gradient output [G]
-    int mode, vec, lpr_log2, pad0;
-    int64_t R, L, nc;         // row modes (block size 256)
-    int64_t C, rps, nbx;      // column mode (rps = rows per block, nbx = blocks along the columns)
-    int col_variant, pad1;
-    int64_t np_pad;           // padded partial count; this task's workspace slice is 3 * np_pad words
-    int64_t ws_off;           // offset of the slice in uint32 words
-    int64_t gstride, n1, stride1, n2;   // finalize geometry
-    double count;             // elements per group
-    uint32_t first_block;     // prefix over traversal blocks
-    uint32_t first_group;     // prefix over groups
-};
-
-__device__ __forceinline__ int find_task(const Task* __restrict__ tasks, int ntasks, uint32_t b, bool by_group) {
-    int lo = 0, hi = ntasks - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        const uint32_t first = by_group ? tasks[mid].first_group : tasks[mid].first_block;
-        if (first <= b) lo = mid;
-        else hi = mid - 1;
-    }
-    return lo;
-}
-
-// Upstream-gradient pointers change every step (autograd allocates them): they travel in the kernel
-// arguments (captured at launch, no staging buffer to race on), at most kBatchMax per launch.
-constexpr int kBatchMax = 256;
-struct PtrPack {
-    const float* dy[kBatchMax];
-};
-
-template <int OP>
-__global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restrict__ tasks, int ntasks, uint32_t* ws, PtrPack pk,
-                                                           int use_pack) {
-    const int ti = find_task(tasks, ntasks, blockIdx.x, false);
-    const Task& t = tasks[ti];
-    Params p = t.p;
-    if (use_pack) p.dy = pk.dy[ti];
-    p.pa = ws + t.ws_off;
-    p.pb = p.pa + t.np_pad;
-    p.pc = reinterpret_cast<float*>(p.pb + t.np_pad);
-    const uint32_t b = blockIdx.x - t.first_block;
-    if (t.mode == 0) {
-        const uint32_t nc = (uint32_t)t.nc;
-        const uint32_t row = b / nc, ck = b - row * nc;
-        const int64_t g = (int64_t)(row % (uint32_t)p.G);
-        if (t.vec) row_stream_body<OP, 4, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
-        else row_stream_body<OP, 1, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
-    } else if (t.mode == 1) {
-        if (t.vec) row_small_body<OP, 4>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
-        else row_small_body<OP, 1>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
-    } else {
-        col_body<OP>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b);
-    }
-}
-
-template <int OP>
-__global__ __launch_bounds__(64) void k_batch_finalize(const Task* __restrict__ tasks, int ntasks, uint32_t* ws) {
-    const int ti = find_task(tasks, ntasks, blockIdx.x, true);
-    const Task& t = tasks[ti];
-    Params p = t.p;
-    p.pa = ws + t.ws_off;
-    p.pb = p.pa + t.np_pad;
-    p.pc = reinterpret_cast<float*>(p.pb + t.np_pad);
-    FinGeom f;
-    f.groups = p.G;
-    f.gstride = t.gstride;
-    f.n1 = t.n1;
-    f.stride1 = t.stride1;
-    f.n2 = t.n2;
-    f.count = t.count;
-    f.o0 = t.ds;
-    f.o1 = nullptr;
-    f.o2 = nullptr;
-    finalize_block_body<OP, 64>(p, f, (int64_t)(blockIdx.x - t.first_group));
-}
-
-// K6 for every scale of the batch in one launch: block per tensor.
-struct AdamTask {
-    float* s;
-    const float* ds;
-    float* m;
-    float* v;
-    int64_t n;
-    float min_value;
-    int pad;
-};
-
-__global__ __launch_bounds__(kBlock) void k_batch_adam(const AdamTask* __restrict__ tasks, float lr, float b1, float b2, double lr_d,
-                                                       double b1_d, double b2_d, float f0, float f1, float eps,
-                                                       const int64_t* step_dev, int64_t step_host, int mode) {
-    const AdamTask t = tasks[blockIdx.x];
-    const int64_t step = step_dev ? step_dev[0] : step_host;
-    float alpha = 0.f, step_size = 0.f, sq_bc2 = 1.f;
-    if (mode == LQ_ADAM_KERAS) {
-        const float b1p = powf(b1, (float)step), b2p = powf(b2, (float)step);
-        alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
-    } else {
-        const double bc1 = 1.0 - pow(b1_d, (double)step), bc2 = 1.0 - pow(b2_d, (double)step);
-        step_size = (float)(lr_d / bc1);
-        sq_bc2 = (float)sqrt(bc2);
-    }
-    for (int64_t i = threadIdx.x; i < t.n; i += kBlock) {
-        const float g = t.ds[i];
-        float mi = t.m[i], vi = t.v[i], w = t.s[i];
-        mi = mi + (g - mi) * f0;
-        vi = vi + (g * g - vi) * f1;
-        if (mode == LQ_ADAM_KERAS) w = w - (mi * alpha) / (sqrtf(vi) + eps);
-        else w = w - step_size * (mi / (sqrtf(vi) / sq_bc2 + eps));
-        w = (w < t.min_value) ? t.min_value : w;
-        t.m[i] = mi;
-        t.v[i] = vi;
-        t.s[i] = w;
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 //  Host side: plan, launchers, C ABI.

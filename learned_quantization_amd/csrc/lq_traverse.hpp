@@ -1,0 +1,507 @@
+// lq_traverse.hpp -- the three traversal modes (row stream, row small, column) and the finalize kernels
+#ifndef LQ_TRAVERSE_HPP_
+#define LQ_TRAVERSE_HPP_
+#include "lq_reduce.hpp"
+
+namespace lq {
+
+// ------------------------------------------------------------------------------------------
+//  Traversal 1 -- "row stream": rows of length L >= 1024.  One block per (row, chunk) unit of
+//  BS*4 elements; every thread owns exactly ONE float4 of each stream (measured on MI355X,
+//  tools/membench.hip: this shape with nontemporal accesses streams 2 reads at 6.8 TB/s, read+write
+//  at 6.5 TB/s, 2 reads + write at 6.5 TB/s; multi-float4-per-thread loops and persistent blocks
+//  are 5-15 % slower).  The scale is block-uniform.  Grid is 3-D (chunk, g, outer) so that no integer
+//  division is needed; a 1-D grid with division is the fallback for huge G / outer.
+//  VEC = 4: float4 accesses (L % 4 == 0 or a single flat row; 16-B aligned bases).
+//  NT: nontemporal loads/stores (streamed-once tensors far larger than the caches).
+// ------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__device__ __forceinline__ float4 load4(const float* p) {
+    if (NT) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+template <int NT>
+__device__ __forceinline__ void store4(float* p, const float4& v) {
+    if (NT) {
+        const v4f t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+    } else {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
+
+template <int OP, int VEC, int BS, int NT, int U = 1>
+__device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int64_t nc, int64_t row, int64_t ck, int64_t g) {
+    using O = OpT<OP>;
+    constexpr int CH = BS * 4 * U;
+    const int64_t base = row * L + ck * (int64_t)CH;
+    const int64_t rem = L - ck * (int64_t)CH;
+    const int len = rem < (int64_t)CH ? (int)rem : CH;
+    Acc acc = O::template init<Acc>();
+
+    if (VEC == 4) {
+        const int len4 = len >> 2;
+        // Issue the streaming loads FIRST (they depend only on the kernel arguments and the block index);
+        // the per-group context (scale fetch, reciprocal, thresholds) is computed while they are in flight.
+        // Inactive lanes of a partial chunk re-read float4 0 of the chunk instead of branching.
+        // A chunk with fewer than 4 elements (len4 == 0; only the last chunk of a flat row, so ck > 0)
+        // reads the float4 just before it: always in bounds, never used.
+        // U = 2 (two float4 per thread and stream) is used when lambda >= 4e-4: every element then takes the
+        // exact-ratio + tanh branch, a wave's compute phase triples, and one float4 per thread no longer keeps
+        // enough bytes in flight per wave-lifetime to stay HBM-bound.
+        int64_t i[U];
+        float4 x[U], d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = u * BS + (int)threadIdx.x;
+            i[u] = base + (int64_t)(j < len4 ? j : 0) * 4;
+            const int64_t il = len4 > 0 ? i[u] : base - 4;
+            x[u] = load4<NT>(p.P + il);
+            d[u] = x[u];
+            if (O::kDy) d[u] = load4<NT>(p.dy + il);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the scale fetch + reciprocal below
+        const Ctx ctx = O::ctx(p, g);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = u * BS + (int)threadIdx.x;
+            if (j < len4) {
+                float4 r;
+                if constexpr (O::kVec4) {
+                    r = O::elem4(p, ctx, i[u], x[u], d[u], acc);
+                } else {
+                    r.x = O::elem(p, ctx, i[u] + 0, x[u].x, O::kDy ? d[u].x : 0.f, acc);
+                    r.y = O::elem(p, ctx, i[u] + 1, x[u].y, O::kDy ? d[u].y : 0.f, acc);
+                    r.z = O::elem(p, ctx, i[u] + 2, x[u].z, O::kDy ? d[u].z : 0.f, acc);
+                    r.w = O::elem(p, ctx, i[u] + 3, x[u].w, O::kDy ? d[u].w : 0.f, acc);
+                }
+                if (O::kStore) store4<NT>(p.out + i[u], r);
+            }
+        }
+        // ragged scalar tail: only a single flat row (G == 1) can have len % 4 != 0 on the vector path
+        const int tail = len & 3;
+        if ((int)threadIdx.x < tail) {
+            const int64_t i = base + (int64_t)len4 * 4 + threadIdx.x;
+            float r = O::elem(p, ctx, i, p.P[i], O::kDy ? p.dy[i] : 0.f, acc);
+            if (O::kStore) p.out[i] = r;
+        }
+    } else {
+        float x[4 * U], d[4 * U];
+#pragma unroll
+        for (int u = 0; u < 4 * U; ++u) {
+            const int j = u * BS + (int)threadIdx.x;
+            const int jc = j < len ? j : len - 1;      // clamp instead of predicate: the loads stay in flight together
+            x[u] = p.P[base + jc];
+            d[u] = O::kDy ? p.dy[base + jc] : 0.f;
+        }
+        const Ctx ctx = O::ctx(p, g);
+#pragma unroll
+        for (int u = 0; u < 4 * U; ++u) {
+            const int j = u * BS + (int)threadIdx.x;
+            if (j < len) {
+                float r = O::elem(p, ctx, base + j, x[u], d[u], acc);
+                if (O::kStore) p.out[base + j] = r;
+            }
+        }
+    }
+    if (O::kReduce) {
+        if constexpr (O::kStdMerge) {
+            block_reduce_dpp<BS>(acc);
+        } else {
+            block_reduce<O, Acc, BS>(acc);
+        }
+        if (threadIdx.x == 0) write_partial(p, row * nc + ck, acc);
+    }
+}
+
+template <int OP, int VEC, int BS, int NT, int U = 1>
+__global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params p, int64_t L, int64_t nc, int grid3d) {
+    int64_t row, ck, g;
+    if (grid3d) {
+        ck = blockIdx.x;
+        g = blockIdx.y;
+        row = (int64_t)blockIdx.z * p.G + g;
+    } else {
+        const int64_t unit = blockIdx.x;
+        row = unit / nc;
+        ck = unit - row * nc;
+        g = row % p.G;
+    }
+    row_stream_body<OP, VEC, BS, NT, U>(p, L, nc, row, ck, g);
+}
+
+// ------------------------------------------------------------------------------------------
+//  Traversal 2 -- "row small": rows of length L < 1024.  A team of 2^lpr_log2 lanes (<= 64,
+//  inside one wave) owns a row; 256 >> lpr_log2 rows per block; one partial per row.
+// ------------------------------------------------------------------------------------------
+template <int OP, int VEC>
+__device__ __forceinline__ void row_small_body(const Params& p, int64_t R, int L, int lpr_log2, int64_t blk) {
+    using O = OpT<OP>;
+    const int lpr = 1 << lpr_log2;
+    const int team = (int)threadIdx.x >> lpr_log2;
+    const int lane = (int)threadIdx.x & (lpr - 1);
+    const int64_t row = blk * (kBlock >> lpr_log2) + team;
+    const bool valid = row < R;
+    Acc acc = O::template init<Acc>();
+    if (valid) {
+        const Ctx ctx = O::ctx(p, row % p.G);
+        const int64_t base = row * (int64_t)L;
+        if (VEC == 4) {   // L % 4 == 0 and 16-B aligned bases: every row starts on a float4 boundary
+            const int L4 = L >> 2;
+#pragma unroll 2
+            for (int j = lane; j < L4; j += lpr) {
+                const int64_t i = base + (int64_t)j * 4;
+                const float4 x = *reinterpret_cast<const float4*>(p.P + i);
+                float4 d = x;
+                if (O::kDy) d = *reinterpret_cast<const float4*>(p.dy + i);
+                float4 r;
+                if constexpr (O::kVec4) {
+                    r = O::elem4(p, ctx, i, x, d, acc);
+                } else {
+                    r.x = O::elem(p, ctx, i + 0, x.x, O::kDy ? d.x : 0.f, acc);
+                    r.y = O::elem(p, ctx, i + 1, x.y, O::kDy ? d.y : 0.f, acc);
+                    r.z = O::elem(p, ctx, i + 2, x.z, O::kDy ? d.z : 0.f, acc);
+                    r.w = O::elem(p, ctx, i + 3, x.w, O::kDy ? d.w : 0.f, acc);
+                }
+                if (O::kStore) *reinterpret_cast<float4*>(p.out + i) = r;
+            }
+        } else {
+#pragma unroll 4
+            for (int j = lane; j < L; j += lpr) {
+                const float x = p.P[base + j];
+                const float d = O::kDy ? p.dy[base + j] : 0.f;
+                float r = O::elem(p, ctx, base + j, x, d, acc);
+                if (O::kStore) p.out[base + j] = r;
+            }
+        }
+    }
+    if (O::kReduce) {
+        wave_reduce<O>(acc, lpr);   // all 64 lanes execute the shuffles; teams never mix (xor < lpr)
+        if (valid && lane == 0) write_partial(p, row, acc);
+    }
+}
+
+template <int OP, int VEC>
+__global__ __launch_bounds__(kBlock) void k_row_small(Params p, int64_t R, int L, int lpr_log2) {
+    row_small_body<OP, VEC>(p, R, L, lpr_log2, (int64_t)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+//  Traversal 3 -- "column": inner < 16 and outer > 1 (column-wise Dense, NHWC per-channel activations).
+//  The tensor is a matrix [outer][C], C = G*inner, the group changes along the contiguous axis.
+//  A block of 4 waves owns a tile of RB rows x (64*VW) columns; a lane keeps VW fixed columns (VW = 4:
+//  one float4 per row, when C % 4 == 0 and the bases are 16-B aligned), so its scales and accumulators
+//  are loop-invariant; wave w walks rows w, w+4, ...; the 4 waves' accumulators meet in LDS and one
+//  partial per (row-block, column) goes to the workspace.  For C <= 64 a whole wave would cover more
+//  than one row: there a wave scans floor(64/C) complete rows per load ("periodic" form, lane -> column
+//  lane % C), which keeps 60-64 of the 64 lanes busy for any C.
+//  (The first version -- one thread per column walking a slice of rows, 4-B loads, no tiling -- reached
+//  1.7 TB/s on a 6144 x 6144 column-wise matrix and 0.25 TB/s on NHWC C = 3.)
+// ------------------------------------------------------------------------------------------
+constexpr int kColUnroll = 4;
+
+template <class O>
+__device__ __forceinline__ void col_cross_wave(Acc* lds, const Acc& mine, int slot, int slots) {
+    lds[(threadIdx.x >> 6) * slots + slot] = mine;
+}
+
+template <int OP, int VW, int NT>
+__device__ __forceinline__ void col_tile_body(const Params& p, int64_t C, int64_t RB, int64_t bx, int64_t by) {
+    using O = OpT<OP>;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t col0 = (bx * 64 + lane) * VW;
+    const bool active = col0 < C;          // VW == 4 implies C % 4 == 0: a float4 never straddles a row end
+    Ctx ctx[VW];
+    Acc acc[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+        acc[k] = O::template init<Acc>();
+        ctx[k] = O::ctx(p, active ? (col0 + k) / p.inner : 0);
+    }
+    const int64_t r0 = by * RB;
+    const int64_t r1 = (r0 + RB < p.outer) ? r0 + RB : p.outer;
+    if (active) {
+        for (int64_t r = r0 + w; r < r1; r += 4 * kColUnroll) {
+            float x[kColUnroll][VW], d[kColUnroll][VW];
+#pragma unroll
+            for (int u = 0; u < kColUnroll; ++u) {
+                const int64_t rr = (r + 4 * u < r1) ? r + 4 * u : r1 - 1;     // clamp: loads stay unconditional
+                const int64_t i = rr * C + col0;
+                if (VW == 4) {
+                    const float4 v = load4<NT>(p.P + i);
+                    x[u][0] = v.x; x[u][1 % VW] = v.y; x[u][2 % VW] = v.z; x[u][3 % VW] = v.w;
+                    if (O::kDy) {
+                        const float4 e = load4<NT>(p.dy + i);
+                        d[u][0] = e.x; d[u][1 % VW] = e.y; d[u][2 % VW] = e.z; d[u][3 % VW] = e.w;
+                    }
+                } else {
+                    x[u][0] = p.P[i];
+                    if (O::kDy) d[u][0] = p.dy[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kColUnroll; ++u) {
+                if (r + 4 * u < r1) {
+                    const int64_t i = (r + 4 * u) * C + col0;
+                    float o[VW];
+#pragma unroll
+                    for (int k = 0; k < VW; ++k) o[k] = O::elem(p, ctx[k], i + k, x[u][k], O::kDy ? d[u][k] : 0.f, acc[k]);
+                    if (O::kStore) {
+                        if (VW == 4) store4<NT>(p.out + i, make_float4(o[0], o[1 % VW], o[2 % VW], o[3 % VW]));
+                        else p.out[i] = o[0];
+                    }
+                }
+            }
+        }
+    }
+    if (O::kReduce) {
+        __shared__ Acc lds[4 * 64 * VW];
+#pragma unroll
+        for (int k = 0; k < VW; ++k) lds[w * (64 * VW) + lane * VW + k] = acc[k];
+        __syncthreads();
+        if (w == 0 && active) {
+#pragma unroll
+            for (int k = 0; k < VW; ++k) {
+                Acc r = lds[lane * VW + k];
+#pragma unroll
+                for (int ww = 1; ww < 4; ++ww) O::merge(r, lds[ww * (64 * VW) + lane * VW + k]);   // fixed wave order
+                write_partial(p, by * C + col0 + k, r);
+            }
+        }
+    }
+}
+
+// C <= 64: lane -> (row rl = lane / C, column c = lane % C); a wave reads k = 64 / C whole rows per load.
+template <int OP>
+__device__ __forceinline__ void col_small_body(const Params& p, int C, int64_t RB, int64_t by) {
+    using O = OpT<OP>;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = 64 / C;
+    const bool active = lane < k * C;
+    const int rl = lane / C, c = lane - rl * C;
+    const Ctx ctx = O::ctx(p, active ? c / p.inner : 0);
+    Acc acc = O::template init<Acc>();
+    const int64_t r0 = by * RB;
+    const int64_t r1 = (r0 + RB < p.outer) ? r0 + RB : p.outer;
+    if (active) {
+        for (int64_t r = r0 + (int64_t)w * k + rl; r < r1; r += (int64_t)4 * k * kColUnroll) {
+            float x[kColUnroll], d[kColUnroll];
+#pragma unroll
+            for (int u = 0; u < kColUnroll; ++u) {
+                const int64_t rq = r + (int64_t)4 * k * u;
+                const int64_t rr = rq < r1 ? rq : r1 - 1;
+                x[u] = p.P[rr * C + c];
+                d[u] = O::kDy ? p.dy[rr * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < kColUnroll; ++u) {
+                const int64_t rq = r + (int64_t)4 * k * u;
+                if (rq < r1) {
+                    const int64_t i = rq * C + c;
+                    const float o = O::elem(p, ctx, i, x[u], d[u], acc);
+                    if (O::kStore) p.out[i] = o;
+                }
+            }
+        }
+    }
+    if (O::kReduce) {
+        __shared__ Acc lds[4 * 64];
+        lds[threadIdx.x] = acc;
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            Acc r = O::template init<Acc>();
+            for (int ww = 0; ww < 4; ++ww)
+                for (int q = 0; q < k; ++q) O::merge(r, lds[ww * 64 + q * C + (int)threadIdx.x]);      // fixed order
+            write_partial(p, by * C + threadIdx.x, r);
+        }
+    }
+}
+
+// variant: 0 = periodic (C <= 64), 1 = tile with scalar columns, 4 = tile with float4 (4 columns per lane),
+// 5 = float4 tile with nontemporal accesses (tensors >= 64 MiB)
+template <int OP>
+__device__ __forceinline__ void col_body(const Params& p, int64_t C, int64_t RB, int64_t nbx, int variant, int64_t b) {
+    if (variant == 0) {
+        col_small_body<OP>(p, (int)C, RB, b);
+    } else {
+        const int64_t by = b / nbx, bx = b - by * nbx;
+        if (variant == 5) col_tile_body<OP, 4, 1>(p, C, RB, bx, by);
+        else if (variant == 4) col_tile_body<OP, 4, 0>(p, C, RB, bx, by);
+        else col_tile_body<OP, 1, 0>(p, C, RB, bx, by);
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_col(Params p, int64_t C, int64_t RB, int64_t nbx, int variant) {
+    col_body<OP>(p, C, RB, nbx, variant, (int64_t)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+//  Finalize: merge the partials of each group in a fixed order (wide accumulator) and emit.
+//  Partial index of group g:  g*gstride + i1*stride1 + i2 ,  i1 < n1, i2 < n2.
+// ------------------------------------------------------------------------------------------
+struct FinGeom {
+    int64_t groups;
+    int64_t gstride, n1, stride1, n2;
+    double count;        // elements per group (outer * inner), or numel for a global reduction
+    float* o0;           // op-specific outputs
+    float* o1;
+    uint32_t* o2;
+};
+
+template <int OP>
+struct FinT;
+
+template <>
+struct FinT<OP_BWD> {
+    __device__ static void emit(const Params& p, const FinGeom& f, int64_t g, const AccW& a) {
+        const float maxq = __uint_as_float(a.a);
+        float mean;
+        if (a.b == 0.0) {
+            mean = -1.0f * fabsf(tanhf(p.lam));                 // custom_layers.py:79 / :105
+        } else {
+            mean = (float)(a.c / f.count);                      // :87 / :113
+        }
+        f.o0[g] = mean * maxq;                                  // :116
+        if (f.o1) {
+            f.o1[g] = maxq;
+            f.o1[f.groups + g] = mean;
+            f.o1[2 * f.groups + g] = (float)a.b;
+        }
+    }
+};
+template <>
+struct FinT<OP_FUSED> : FinT<OP_BWD> {};
+
+template <>
+struct FinT<OP_MAXBIN_FWD> {
+    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
+        f.o0[g] = __uint_as_float(a.a);
+        f.o2[g] = (uint32_t)(a.b > 4294967295.0 ? 4294967295.0 : a.b);
+    }
+};
+
+template <>
+struct FinT<OP_DIFF_FWD> {
+    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
+        f.o0[g] = (float)(a.c / f.count);                       // custom_loss_functions.py:175 reduce_mean
+    }
+};
+
+template <>
+struct FinT<OP_DIFF_BWD> {
+    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
+        f.o0[g] = (float)a.c;
+    }
+};
+
+template <class O>
+__device__ __forceinline__ AccW load_partial(const Params& p, int64_t idx) {
+    AccW w;
+    w.a = p.pa[idx];
+    w.b = (double)p.pb[idx];
+    w.c = (double)p.pc[idx];
+    return w;
+}
+
+// DPP reduction of the wide standard accumulator (max, add, add); same lane pattern as dpp_wave_reduce.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)u);
+    const uint32_t hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(u >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_step_w(AccW& acc) {
+    const uint32_t a = dpp_u32<CTRL, ROW_MASK>(0u, acc.a);
+    const double b = dpp_f64<CTRL, ROW_MASK>(acc.b);
+    const double c = dpp_f64<CTRL, ROW_MASK>(acc.c);
+    acc.a = a > acc.a ? a : acc.a;
+    acc.b += b;
+    acc.c += c;
+}
+__device__ __forceinline__ void dpp_row_reduce_w(AccW& acc) {
+    dpp_step_w<0xB1, 0xf>(acc);
+    dpp_step_w<0x4E, 0xf>(acc);
+    dpp_step_w<0x141, 0xf>(acc);
+    dpp_step_w<0x140, 0xf>(acc);
+}
+
+// One block of BS threads per group.  Index arithmetic is 32-bit whenever the partial count allows (a 64-bit
+// division per loaded partial used to dominate this kernel).
+template <int OP, int BS>
+__device__ __forceinline__ void finalize_block_body(const Params& p, const FinGeom& f, int64_t g) {
+    using O = OpT<OP>;
+    const int64_t n = f.n1 * f.n2;
+    const int64_t gbase = g * f.gstride;
+    AccW acc = O::template init<AccW>();
+    if (n < 0x7fffffffll) {
+        const uint32_t n32 = (uint32_t)n, n2 = (uint32_t)f.n2;
+        for (uint32_t k = threadIdx.x; k < n32; k += BS) {
+            const uint32_t i1 = k / n2, i2 = k - i1 * n2;
+            O::merge(acc, load_partial<O>(p, gbase + (int64_t)i1 * f.stride1 + i2));
+        }
+    } else {
+        for (int64_t k = threadIdx.x; k < n; k += BS) {
+            const int64_t i1 = k / f.n2, i2 = k - i1 * f.n2;
+            O::merge(acc, load_partial<O>(p, gbase + i1 * f.stride1 + i2));
+        }
+    }
+    if constexpr (O::kStdMerge) {
+        constexpr int NW = BS / 64;
+        __shared__ uint32_t sa[NW];
+        __shared__ double sb[NW], sc[NW];
+        dpp_row_reduce_w(acc);
+        dpp_step_w<0x142, 0xa>(acc);
+        dpp_step_w<0x143, 0xc>(acc);
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        if (NW > 1) {
+            if (lane == 63) {
+                sa[wid] = acc.a;
+                sb[wid] = acc.b;
+                sc[wid] = acc.c;
+            }
+            __syncthreads();
+            if (wid == 0) {
+                AccW r;
+                r.a = lane < NW ? sa[lane] : 0u;
+                r.b = lane < NW ? sb[lane] : 0.0;
+                r.c = lane < NW ? sc[lane] : 0.0;
+                dpp_row_reduce_w(r);
+                if (lane == 0) FinT<OP>::emit(p, f, g, r);
+            }
+        } else if (lane == 63) {
+            FinT<OP>::emit(p, f, g, acc);
+        }
+    } else {
+        block_reduce<O, AccW, BS>(acc);
+        if (threadIdx.x == 0) FinT<OP>::emit(p, f, g, acc);
+    }
+}
+
+template <int OP, int BS>
+__global__ __launch_bounds__(BS) void k_finalize_block(Params p, FinGeom f) {
+    finalize_block_body<OP, BS>(p, f, (int64_t)blockIdx.x);
+}
+
+// One thread per group (few partials per group, possibly very many groups).
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_finalize_thread(Params p, FinGeom f) {
+    using O = OpT<OP>;
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= f.groups) return;
+    AccW acc = O::template init<AccW>();
+    for (int64_t i1 = 0; i1 < f.n1; ++i1)
+        for (int64_t i2 = 0; i2 < f.n2; ++i2) O::merge(acc, load_partial<O>(p, g * f.gstride + i1 * f.stride1 + i2));
+    FinT<OP>::emit(p, f, g, acc);
+}
+
+}  // namespace lq
+
+#endif

@@ -155,7 +155,7 @@ def test_product_code_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "learned_quantization_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
                 assert "lq_oracle" not in src, f"{f} references the oracle"
