@@ -139,3 +139,32 @@ def test_inf_and_huge_values_take_the_ieee_path(dev):
         np.testing.assert_array_equal(out.cpu().numpy(), out_o)
         # sign of zero is preserved exactly (bit pattern), like IEEE division
         np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), out_o.view(np.uint32))
+
+
+def test_pathological_scales(dev):
+    """Zero, negative, denormal, infinite and NaN scales: outside the constraint of the reference (s >= 100*eps), but the op
+    must still be the same three IEEE operations as the oracle -- including where NaN / Inf appear."""
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(5)
+    P = rng.normal(0, 1.0, size=(6, 2048)).astype(np.float32)
+    P[0, :8] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-40, -1e-40, 3e38]
+    dy = rng.normal(0, 1e-3, size=P.shape).astype(np.float32)
+    s = np.array([[0.0], [-0.25], [1e-41], [np.inf], [np.nan], [3e38]], np.float32)
+    with np.errstate(all="ignore"):
+        q_o, out_o = O.fq_forward(P, s)
+        _, ds_o, im = O.nq_backward(P, s, 1e-3, dy, return_intermediates=True)
+    out, q = lq.fq_forward(_t(P, dev), _t(s, dev), q_dtype=torch.float32)
+    np.testing.assert_array_equal(q.cpu().numpy(), q_o)                      # NaN == NaN positionally in assert_array_equal
+    np.testing.assert_array_equal(out.cpu().numpy(), out_o)
+    ds = lq.fq_scale_grad(_t(P, dev), _t(s, dev), _t(dy, dev), 1e-3).cpu().numpy()
+    assert np.array_equal(np.isnan(ds), np.isnan(ds_o))
+    fin = ~np.isnan(ds_o)
+    np.testing.assert_allclose(ds[fin], ds_o[fin], rtol=RTOL)
+    # the same rows through the small-row and column traversals
+    P2 = np.ascontiguousarray(P[:, :48])
+    dy2 = np.ascontiguousarray(dy[:, :48])
+    with np.errstate(all="ignore"):
+        _, out2_o = O.fq_forward(P2, s)
+        _, out3_o = O.fq_forward(np.ascontiguousarray(P2.T), s.reshape(1, 6))
+    np.testing.assert_array_equal(lq.fq_forward(_t(P2, dev), _t(s, dev)).cpu().numpy(), out2_o)
+    np.testing.assert_array_equal(lq.fq_forward(_t(np.ascontiguousarray(P2.T), dev), _t(s.reshape(1, 6), dev)).cpu().numpy(), out3_o)

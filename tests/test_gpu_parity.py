@@ -260,3 +260,18 @@ def test_window_division_selftest(dev):
         _hip.check(lib.lq_selftest_ratio_division(seed, 8192, 1024, bad.data_ptr(), None), "selftest")
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
+
+
+@pytest.mark.parametrize("orient", ["rowwise", "columnwise", "scalar"])
+def test_mnist_real_weights_backward(mnist_weights, dev, orient):
+    """Scale gradient on the shipped MNIST baseline weights (realistic distribution, |w| <= 0.23) at the thresholds the
+    thesis sweeps, with gradient magnitudes of a trained net (1e-6 .. 1e-2)."""
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(12)
+    for name in ("W1", "W2"):
+        P = mnist_weights[name]
+        sshape = O.scale_shape(P.shape, orient)
+        s = (np.abs(P).max() / rng.uniform(8, 40, size=sshape)).astype(np.float32)
+        dy = (rng.normal(0, 1, size=P.shape) * 10.0 ** rng.uniform(-6, -2, size=P.shape)).astype(np.float32)
+        for lam in (1e-11, 1e-10, 1e-6, 1e-3):
+            _check_case(P, s, dy, lam, dev, f"{name} {orient} lam={lam}")
