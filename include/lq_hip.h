@@ -188,6 +188,17 @@ int lq_batch_scale_grad(const lq_batch* batch, const float* const* dy, void* ws,
 int lq_batch_scale_adam(const lq_batch* batch, double lr, double beta1, double beta2, double eps, int64_t step,
                         const int64_t* step_dev, int mode, void* stream);
 
+/* Custom-loss-term gradients of every tensor of the batch in 2-4 launches
+ *   (CIFAR-10/custom_loss_terms/custom_components/custom_loss_functions.py:75-116, 161-195, 240-275).
+ * The total loss is mean(SCCE) + gamma * penalty (:58), so the upstream coefficient of tensor i's term is the HOST
+ * constant coeff[i] = gamma * numel_i / normalizer -- no autograd node per tensor is needed:
+ *   grad[i][...] += coeff[i] * d term_i / d P_i     (MaxBin, Difference; accumulated into the existing gradient)
+ *   ds_i[...]     = coeff[i] * d term_i / d s_i     (written to the descriptors' ds buffers)
+ * coeff: host array [n]; grad: host array [n] of device pointers (unused for LQ_PENALTY_INVERSE).                 */
+typedef enum lq_penalty_kind { LQ_PENALTY_MAXBIN = 0, LQ_PENALTY_DIFFERENCE = 1, LQ_PENALTY_INVERSE = 2 } lq_penalty_kind;
+int lq_batch_penalty_grads(const lq_batch* batch, int kind, const float* coeff, float* const* grad,
+                           void* ws, size_t ws_bytes, void* stream);
+
 /* ---- integer-view range and histogram (tracking callbacks) -----------------------------------------
  * The reference's callbacks pull floor(P/s) to the host and run np.unique on it every epoch
  *   CIFAR-10/nested_quantization_layer/custom_components/custom_callbacks.py:85-96, 131-207.

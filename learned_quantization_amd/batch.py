@@ -112,6 +112,33 @@ class FakeQuantBatch:
             layer._q_pre = (qk, qb)
         return outs
 
+    # ------------------------------------------------------------------ custom loss terms
+    _KINDS = {"maxbin": 0, "difference": 1, "inverse": 2}
+
+    def inject_penalty_grads(self, kind: str, penalty_rate: float):
+        """Adds d(penalty_rate * penalty)/dP to every ``P.grad`` and writes d(...)/ds to every ``scale.grad`` in 2-4
+        launches.  Call after ``loss.backward()`` of the task loss alone: the reference's objective is
+        ``mean(SCCE) + penalty_rate * penalty`` (custom_loss_functions.py:58), so the coefficient of tensor i's term
+        ``mean(...)_i`` is the constant ``penalty_rate * numel_i / sum(numel)`` (:110-116) and no autograd node per tensor
+        is needed.  Equivalent to differentiating ``SCCE*.compute_total_loss`` (tests/test_gpu_batch.py)."""
+        lib = _hip.load()
+        n = len(self.entries)
+        normalizer = float(sum(e.param.numel() for e in self.entries))
+        coeff = (ctypes.c_float * n)(*[float(penalty_rate) * e.param.numel() / normalizer for e in self.entries])
+        grads = (ctypes.c_void_p * n)()
+        for i, e in enumerate(self.entries):
+            if kind != "inverse":
+                g = e.param.grad
+                if g is None:
+                    g = e.param.grad = torch.zeros_like(e.param.data)
+                if not g.is_contiguous():
+                    raise ValueError("parameter gradients must be contiguous")
+                grads[i] = g.data_ptr()
+        _hip.check(lib.lq_batch_penalty_grads(self._handle, self._KINDS[kind], coeff, grads, _hip.ptr(self.ws), self.ws.numel(),
+                                              _hip.stream_ptr(self.device)), "lq_batch_penalty_grads")
+        for e in self.entries:
+            e.nested.scale.grad = e.ds
+
     # ------------------------------------------------------------------ optimizer
     def scale_adam_step(self, step: Optional[int] = None, step_dev: Optional[torch.Tensor] = None):
         lib = _hip.load()

@@ -15,6 +15,8 @@ namespace lq {
 struct Task {
     Params p;                 // pa/pb/pc are rebound to the batch workspace inside the kernel
     float* ds;                // scale gradient output [G]
+    float* mb;                // batch-owned per-group max(|P|/s)      (MaxBin penalty)
+    uint32_t* ties;           // batch-owned per-group tie counts
     int mode, vec, lpr_log2, pad0;
     int64_t R, L, nc;         // row modes (block size 256)
     int64_t C, rps, nbx;      // column mode (rps = rows per block, nbx = blocks along the columns)
@@ -44,14 +46,27 @@ constexpr int kBatchMax = 256;
 struct PtrPack {
     const float* dy[kBatchMax];
 };
+struct CoefPack {           // per-tensor upstream coefficient of a penalty term (host constants)
+    float c[kBatchMax];
+};
 
+// use_pack: 0 = pointers from the task table; 1 = pk.dy[] are the upstream gradients (scale-gradient pass);
+//           2 = penalty pass: pk.dy[] are the gradient buffers to ACCUMULATE into, cf.c[] the upstream coefficients
 template <int OP>
 __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restrict__ tasks, int ntasks, uint32_t* ws, PtrPack pk,
-                                                           int use_pack) {
+                                                           int use_pack, CoefPack cf) {
     const int ti = find_task(tasks, ntasks, blockIdx.x, false);
     const Task& t = tasks[ti];
     Params p = t.p;
-    if (use_pack) p.dy = pk.dy[ti];
+    if (use_pack == 1) p.dy = pk.dy[ti];
+    if (use_pack == 2) {
+        p.out = const_cast<float*>(pk.dy[ti]);
+        p.accum = 1;
+        p.c_dev = nullptr;
+        p.c_scale = cf.c[ti];
+        p.mb = t.mb;
+        p.ties = t.ties;
+    }
     p.pa = ws + t.ws_off;
     p.pb = p.pa + t.np_pad;
     p.pc = reinterpret_cast<float*>(p.pb + t.np_pad);
@@ -85,10 +100,25 @@ __global__ __launch_bounds__(64) void k_batch_finalize(const Task* __restrict__ 
     f.stride1 = t.stride1;
     f.n2 = t.n2;
     f.count = t.count;
-    f.o0 = t.ds;
+    f.o0 = (OP == OP_MAXBIN_FWD) ? t.mb : t.ds;
     f.o1 = nullptr;
-    f.o2 = nullptr;
+    f.o2 = (OP == OP_MAXBIN_FWD) ? t.ties : nullptr;
     finalize_block_body<OP, 64>(p, f, (int64_t)(blockIdx.x - t.first_group));
+}
+
+// Scale gradients of the MaxBin (kind 0) and Inverse (kind 2) penalty terms for every group of every tensor:
+//   maxbin   ds[g] = -((c/G) * mb[g]) / s[g]          (custom_loss_functions.py:92,110; reduce_max + RealDiv gradients)
+//   inverse  ds[g] = s[g] == 0 ? 0 : -((c/G) / s[g]) / s[g]                     (:252-255)
+__global__ __launch_bounds__(kBlock) void k_batch_penalty_ds(const Task* __restrict__ tasks, int ntasks, uint32_t total_groups, int kind,
+                                                             CoefPack cf) {
+    const uint32_t gg = blockIdx.x * kBlock + threadIdx.x;
+    if (gg >= total_groups) return;
+    const int ti = find_task(tasks, ntasks, gg, true);
+    const Task& t = tasks[ti];
+    const uint32_t g = gg - t.first_group;
+    const float up = cf.c[ti], sg = t.p.s[g], G = (float)t.p.G;
+    if (kind == 0) t.ds[g] = -((up / G) * t.mb[g]) / sg;
+    else t.ds[g] = (sg == 0.0f) ? 0.0f : -((up / G) / sg) / sg;
 }
 
 // K6 for every scale of the batch in one launch: block per tensor.

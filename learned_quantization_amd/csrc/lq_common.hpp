@@ -29,6 +29,7 @@ struct Params {
     const uint32_t* ties;
     const float* c_dev;  // upstream gradient, device scalar
     float c_scale;
+    int accum;           // penalty backward: add to the existing contents of `out` instead of overwriting
     uint32_t* pa;        // partials, SoA
     uint32_t* pb;
     float* pc;

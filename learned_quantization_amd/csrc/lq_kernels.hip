@@ -588,13 +588,16 @@ int lq_q_absmax_over_axis(const float* P, const float* s, float* result, int64_t
 // ------------------------------------------------------------------------------------------
 struct lq_batch {
     int n = 0;
-    std::vector<lq::Task> fwd_h, bwd_h;
+    std::vector<lq::Task> fwd_h, bwd_h, pen_h;
     std::vector<int> bwd_index;          // bwd task -> descriptor index
     std::vector<lq::AdamTask> adam_h;
     lq::Task* fwd_d = nullptr;
     lq::Task* bwd_d = nullptr;
+    lq::Task* pen_d = nullptr;           // every tensor, with workspace slices and mb/ties buffers (penalty passes)
+    float* mb_d = nullptr;
+    uint32_t* ties_d = nullptr;
     lq::AdamTask* adam_d = nullptr;
-    uint32_t fwd_blocks = 0, bwd_blocks = 0, bwd_groups = 0;
+    uint32_t fwd_blocks = 0, bwd_blocks = 0, bwd_groups = 0, pen_blocks = 0, pen_groups = 0;
     size_t ws_bytes = 256;
 };
 
@@ -660,7 +663,7 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
     lq_batch* b = new (std::nothrow) lq_batch();
     if (!b) return fail(LQ_EHIP, "lq_batch_create: out of host memory");
     b->n = n;
-    int64_t ws_words = 0, dummy = 0;
+    int64_t ws_words = 0, dummy = 0, pen_words = 0;
     uint32_t gp_dummy = 0;
     for (int i = 0; i < n; ++i) {
         const lq_tensor_desc& d = descs[i];
@@ -674,6 +677,15 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
             return rc;
         }
         b->fwd_h.push_back(t);
+        if (d.ds) {                   // penalty passes need a scale-gradient destination
+            Task tp;
+            rc = fill_task(tp, d, true, b->pen_blocks, b->pen_groups, pen_words);
+            if (rc) {
+                delete b;
+                return rc;
+            }
+            b->pen_h.push_back(tp);
+        }
         if (d.lambda == d.lambda) {   // not NaN: nested-quantization tensor with a scale gradient
             if (!d.ds) {
                 delete b;
@@ -704,12 +716,24 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
             b->adam_h.push_back(a);
         }
     }
-    b->ws_bytes = (size_t)ws_words * 4 + 256;
+    b->ws_bytes = (size_t)(ws_words > pen_words ? ws_words : pen_words) * 4 + 256;
     hipError_t e = hipMalloc(&b->fwd_d, b->fwd_h.size() * sizeof(Task));
     if (e == hipSuccess) e = hipMemcpy(b->fwd_d, b->fwd_h.data(), b->fwd_h.size() * sizeof(Task), hipMemcpyHostToDevice);
     if (e == hipSuccess && !b->bwd_h.empty()) {
         e = hipMalloc(&b->bwd_d, b->bwd_h.size() * sizeof(Task));
         if (e == hipSuccess) e = hipMemcpy(b->bwd_d, b->bwd_h.data(), b->bwd_h.size() * sizeof(Task), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !b->pen_h.empty()) {
+        e = hipMalloc(&b->mb_d, (size_t)b->pen_groups * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&b->ties_d, (size_t)b->pen_groups * sizeof(uint32_t));
+        if (e == hipSuccess) {
+            for (auto& tp : b->pen_h) {
+                tp.mb = b->mb_d + tp.first_group;
+                tp.ties = b->ties_d + tp.first_group;
+            }
+            e = hipMalloc(&b->pen_d, b->pen_h.size() * sizeof(Task));
+        }
+        if (e == hipSuccess) e = hipMemcpy(b->pen_d, b->pen_h.data(), b->pen_h.size() * sizeof(Task), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess && !b->adam_h.empty()) {
         e = hipMalloc(&b->adam_d, b->adam_h.size() * sizeof(AdamTask));
@@ -729,6 +753,9 @@ int lq_batch_destroy(lq_batch* b) {
     if (b->fwd_d) (void)hipFree(b->fwd_d);
     if (b->bwd_d) (void)hipFree(b->bwd_d);
     if (b->adam_d) (void)hipFree(b->adam_d);
+    if (b->pen_d) (void)hipFree(b->pen_d);
+    if (b->mb_d) (void)hipFree(b->mb_d);
+    if (b->ties_d) (void)hipFree(b->ties_d);
     delete b;
     return LQ_OK;
 }
@@ -738,8 +765,9 @@ size_t lq_batch_workspace_bytes(const lq_batch* b) { return b ? b->ws_bytes : 0;
 int lq_batch_forward(const lq_batch* b, void* stream) {
     if (!b) return fail(LQ_EINVAL, "lq_batch_forward: NULL batch");
     PtrPack pk;
+    CoefPack cf;
     hipLaunchKernelGGL((k_batch_traverse<OP_FWD>), dim3(b->fwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->fwd_d,
-                       (int)b->fwd_h.size(), (uint32_t*)nullptr, pk, 0);
+                       (int)b->fwd_h.size(), (uint32_t*)nullptr, pk, 0, cf);
     return check_hip("batch forward launch");
 }
 
@@ -762,13 +790,56 @@ int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, siz
         pk.dy[i] = d;
     }
     if (!all_aligned) return fail(LQ_EALIGN, "lq_batch_scale_grad: a 16-byte aligned tensor got a dy that is not 16-byte aligned");
+    CoefPack cf;
     hipLaunchKernelGGL((k_batch_traverse<OP_BWD>), dim3(b->bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->bwd_d,
-                       (int)b->bwd_h.size(), (uint32_t*)ws, pk, 1);
+                       (int)b->bwd_h.size(), (uint32_t*)ws, pk, 1, cf);
     int rc = check_hip("batch scale-grad launch");
     if (rc) return rc;
     hipLaunchKernelGGL((k_batch_finalize<OP_BWD>), dim3(b->bwd_groups), dim3(64), 0, (hipStream_t)stream, b->bwd_d,
                        (int)b->bwd_h.size(), (uint32_t*)ws);
     return check_hip("batch finalize launch");
+}
+
+int lq_batch_penalty_grads(const lq_batch* b, int kind, const float* coeff, float* const* grad, void* ws, size_t ws_bytes,
+                           void* stream) {
+    if (!b) return fail(LQ_EINVAL, "lq_batch_penalty_grads: NULL batch");
+    if (kind < LQ_PENALTY_MAXBIN || kind > LQ_PENALTY_INVERSE) return fail(LQ_EINVAL, "lq_batch_penalty_grads: bad kind %d", kind);
+    if (!coeff) return fail(LQ_EINVAL, "lq_batch_penalty_grads: coeff is NULL");
+    if (b->pen_h.size() != (size_t)b->n) return fail(LQ_EINVAL, "lq_batch_penalty_grads: every tensor of the batch needs a ds buffer");
+    CoefPack cf;
+    PtrPack pk;
+    memset(&pk, 0, sizeof(pk));
+    memset(&cf, 0, sizeof(cf));
+    for (int i = 0; i < b->n; ++i) cf.c[i] = coeff[i];
+    const int nt = (int)b->pen_h.size();
+    hipStream_t st = (hipStream_t)stream;
+    if (kind != LQ_PENALTY_INVERSE) {
+        if (!grad) return fail(LQ_EINVAL, "lq_batch_penalty_grads: grad pointers are NULL");
+        if (!ws) return fail(LQ_EWORKSPACE, "lq_batch_penalty_grads: workspace is NULL (need %zu bytes)", b->ws_bytes);
+        if (!aligned(ws, 16)) return fail(LQ_EALIGN, "lq_batch_penalty_grads: workspace must be 16-byte aligned");
+        if (ws_bytes < b->ws_bytes) return fail(LQ_EWORKSPACE, "lq_batch_penalty_grads: workspace too small: %zu < %zu bytes", ws_bytes, b->ws_bytes);
+        for (int i = 0; i < b->n; ++i) {
+            if (!grad[i] || !aligned(grad[i], 4)) return fail(LQ_EINVAL, "lq_batch_penalty_grads: gradient buffer of tensor %d missing", i);
+            const Task& t = b->pen_h[i];
+            const bool wants16 = (t.mode != MODE_COL && t.vec) || (t.mode == MODE_COL && t.col_variant >= 4);
+            if (wants16 && !aligned(grad[i], 16)) return fail(LQ_EALIGN, "lq_batch_penalty_grads: gradient buffer of tensor %d is not 16-byte aligned", i);
+            pk.dy[i] = grad[i];
+        }
+    }
+    if (kind == LQ_PENALTY_MAXBIN) {
+        PtrPack none;
+        memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_FWD>), dim3(b->pen_blocks), dim3(kBlock), 0, st, b->pen_d, nt, (uint32_t*)ws, none, 0, cf);
+        hipLaunchKernelGGL((k_batch_finalize<OP_MAXBIN_FWD>), dim3(b->pen_groups), dim3(64), 0, st, b->pen_d, nt, (uint32_t*)ws);
+        hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_BWD>), dim3(b->pen_blocks), dim3(kBlock), 0, st, b->pen_d, nt, (uint32_t*)ws, pk, 2, cf);
+        hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(b->pen_groups, kBlock)), dim3(kBlock), 0, st, b->pen_d, nt, b->pen_groups, 0, cf);
+    } else if (kind == LQ_PENALTY_DIFFERENCE) {
+        hipLaunchKernelGGL((k_batch_traverse<OP_DIFF_BWD>), dim3(b->pen_blocks), dim3(kBlock), 0, st, b->pen_d, nt, (uint32_t*)ws, pk, 2, cf);
+        hipLaunchKernelGGL((k_batch_finalize<OP_DIFF_BWD>), dim3(b->pen_groups), dim3(64), 0, st, b->pen_d, nt, (uint32_t*)ws);
+    } else {
+        hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(b->pen_groups, kBlock)), dim3(kBlock), 0, st, b->pen_d, nt, b->pen_groups, 2, cf);
+    }
+    return check_hip("batch penalty launch");
 }
 
 int lq_batch_scale_adam(const lq_batch* b, double lr, double beta1, double beta2, double eps, int64_t step,

@@ -155,14 +155,15 @@ struct OpT<OP_MAXBIN_BWD> : OpBase {
         c.lam_hi = 0.f;
         c.sure_ok = 0;
         c.k0 = p.mb[g];
-        float up = p.c_dev[0] * p.c_scale;
+        float up = (p.c_dev ? p.c_dev[0] : 1.0f) * p.c_scale;
         c.k1 = (up / (float)p.G) / (float)p.ties[g];
         return c;
     }
-    __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc&) {
+    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float, Acc&) {
         float t = fabsf(fabsf(x) / c.s);
         float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-        return (t == c.k0) ? (c.k1 / c.s) * sgn : 0.f;
+        const float g = (t == c.k0) ? (c.k1 / c.s) * sgn : 0.f;
+        return p.accum ? p.out[i] + g : g;
     }
 };
 
@@ -190,17 +191,18 @@ struct OpT<OP_DIFF_BWD> : OpBase {
         c.lam_hi = 0.f;
         c.sure_ok = 0;
         double n = (double)p.outer * (double)p.G * (double)p.inner;
-        c.k0 = (p.c_dev[0] * p.c_scale) / (float)n;
+        c.k0 = ((p.c_dev ? p.c_dev[0] : 1.0f) * p.c_scale) / (float)n;
         c.k1 = 0.f;
         return c;
     }
-    __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc& acc) {
+    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float, Acc& acc) {
         float pq = x / c.s;
         float u = x - pq;
         float sgn = (u > 0.f) ? 1.f : ((u < 0.f) ? -1.f : 0.f);
         float gi = sgn * c.k0;
         acc.c += (gi * pq) / c.s;
-        return gi - gi / c.s;
+        const float g = gi - gi / c.s;
+        return p.accum ? p.out[i] + g : g;
     }
 };
 

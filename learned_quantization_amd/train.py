@@ -54,6 +54,7 @@ class Trainer:
         self.model.to(self.device)
         self.custom_layers = L.custom_layers_of(self.model)
         self.loss_obj = None
+        self.loss_kind, self.penalty_rate = loss, value
         if mode == "cl":
             if loss not in LOSSES:
                 raise ValueError("mode 'cl' needs --loss maxbin|difference|inverse")
@@ -78,7 +79,7 @@ class Trainer:
         self._want_graph = graph
 
     def loss(self, y, p):
-        if self.loss_obj is not None:
+        if self.loss_obj is not None and self.batch is None:
             per_sample = self.loss_obj.compute_total_loss(y, p)
         else:
             per_sample = sparse_categorical_crossentropy(y, p)
@@ -98,6 +99,10 @@ class Trainer:
             self.batch.quantize_all()
         loss = self.loss(y, self.model(x))
         loss.backward()
+        if self.batch is not None and self.loss_obj is not None:
+            # batched custom-loss-terms mode: the task loss went through autograd, the penalty gradients are injected
+            # by the batch kernels (identical on every rank, so adding them before the all-reduce changes nothing)
+            self.batch.inject_penalty_grads(self.loss_kind, self.penalty_rate)
         if self.dp is not None:
             self.dp.sync_gradients()
         self.opt.step()

@@ -98,3 +98,44 @@ def test_batch_ste_only_tensors_and_errors(dev):
     m.convs[0].kernel.data = m.convs[0].kernel.data.clone()    # re-allocation must be detected, not silently stale
     with pytest.raises(RuntimeError, match="re-allocated"):
         batch.quantize_all()
+
+
+@pytest.mark.parametrize("kind", ["maxbin", "difference", "inverse"])
+@pytest.mark.parametrize("orient", ["rowwise", "columnwise", "channelwise", "scalar"])
+def test_injected_penalty_grads_equal_autograd_of_the_loss_object(dev, kind, orient, tmp_path):
+    """lq_batch_penalty_grads == autograd through SCCE*.compute_total_loss (which itself is checked against the oracle)."""
+    import learned_quantization_amd as lq
+    gamma = 0.37
+    m = _model(dev, "cifar", orient, mode="cl", value=gamma)
+    layers = lq.custom_layers_of(m)
+    cls = {"maxbin": lq.SCCEMaxBin, "difference": lq.SCCEDifference, "inverse": lq.SCCEInverse}[kind]
+    loss_obj = cls(layers, gamma, str(tmp_path))
+    y = torch.tensor([1, 0, 3], device=dev)
+    p = torch.softmax(torch.randn(3, 10, device=dev), dim=1)
+    loss_obj.compute_total_loss(y, p).mean().backward()
+    want = {}
+    for l in layers:
+        want[l.name] = (None if l.kernel.grad is None else l.kernel.grad.clone(), None if l.b.grad is None else l.b.grad.clone(),
+                        l.nested_q_k_layer.scale.grad.clone(), l.nested_q_b_layer.scale.grad.clone())
+        l.kernel.grad = None
+        l.b.grad = None
+        l.nested_q_k_layer.scale.grad = None
+        l.nested_q_b_layer.scale.grad = None
+    batch = lq.FakeQuantBatch(m)
+    g = torch.Generator(device=dev).manual_seed(3)
+    seeds = {}
+    for l in layers:                       # pretend the task loss already left gradients: the injection must ADD to them
+        l.kernel.grad = torch.randn(l.kernel.shape, device=dev, generator=g) * 1e-3
+        l.b.grad = torch.randn(l.b.shape, device=dev, generator=g) * 1e-3
+        seeds[l.name] = (l.kernel.grad.clone(), l.b.grad.clone())
+    batch.inject_penalty_grads(kind, gamma)
+    for l in layers:
+        wk, wb, wsk, wsb = want[l.name]
+        sk, sb = seeds[l.name]
+        if kind != "inverse":
+            np.testing.assert_allclose((l.kernel.grad - sk).cpu().numpy(), wk.cpu().numpy(), rtol=1e-4, atol=1e-9, err_msg=f"{l.name} dK")
+            np.testing.assert_allclose((l.b.grad - sb).cpu().numpy(), wb.cpu().numpy(), rtol=1e-4, atol=1e-9, err_msg=f"{l.name} db")
+        else:
+            assert torch.equal(l.kernel.grad, sk) and torch.equal(l.b.grad, sb)
+        np.testing.assert_allclose(l.nested_q_k_layer.scale.grad.cpu().numpy(), wsk.cpu().numpy(), rtol=1e-4, atol=1e-12, err_msg=f"{l.name} ds_k")
+        np.testing.assert_allclose(l.nested_q_b_layer.scale.grad.cpu().numpy(), wsb.cpu().numpy(), rtol=1e-4, atol=1e-12, err_msg=f"{l.name} ds_b")
