@@ -35,6 +35,7 @@ class FakeQuantBatch:
     def __init__(self, model_or_layers, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-7, mode: str = "keras"):
         layers = custom_layers_of(model_or_layers) if isinstance(model_or_layers, torch.nn.Module) else list(model_or_layers)
         self.layers = layers
+        self._external_grads = False
         self.entries: List[_Entry] = []
         for layer in layers:
             if isinstance(layer, _ConvBase):
@@ -55,7 +56,11 @@ class FakeQuantBatch:
                 e.out = torch.empty_like(param.data)
                 # write straight into an existing gradient buffer (e.g. a DataParallel bucket view) when there is one
                 g = nested.scale.grad
-                e.ds = g if (g is not None and g.is_contiguous()) else torch.zeros_like(nested.scale.data)
+                if g is not None and g.is_contiguous():
+                    e.ds = g                       # external buffer (bucket view): zeroed by its owner, never set to None
+                    self._external_grads = True
+                else:
+                    e.ds = torch.zeros_like(nested.scale.data)
                 e.m = torch.zeros_like(nested.scale.data)
                 e.v = torch.zeros_like(nested.scale.data)
                 e.desc = group_descriptor(tuple(param.shape), tuple(nested.scale.shape))
@@ -174,6 +179,12 @@ class _BatchFn(torch.autograd.Function):
         for e, d in zip(batch.entries, keep):
             grads.append(d)                                        # dP is dy itself (custom_layers.py:118)
             if e.nested.penalty_threshold is not None:
+                g = e.nested.scale.grad
+                if g is not None and not batch._external_grads:
+                    # the kernel OVERWRITES its gradient buffer: a second backward without zero_grad(set_to_none=True)
+                    # would silently drop the first gradient -- refuse instead
+                    raise RuntimeError("FakeQuantBatch: scale gradients must be None before backward "
+                                       "(gradient accumulation over several backward passes is not supported in batched mode)")
                 e.nested.scale.grad = e.ds                         # written in place by the kernel: no accumulate launch
                 grads.append(None)
             else:

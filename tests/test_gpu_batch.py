@@ -139,3 +139,14 @@ def test_injected_penalty_grads_equal_autograd_of_the_loss_object(dev, kind, ori
             assert torch.equal(l.kernel.grad, sk) and torch.equal(l.b.grad, sb)
         np.testing.assert_allclose(l.nested_q_k_layer.scale.grad.cpu().numpy(), wsk.cpu().numpy(), rtol=1e-4, atol=1e-12, err_msg=f"{l.name} ds_k")
         np.testing.assert_allclose(l.nested_q_b_layer.scale.grad.cpu().numpy(), wsb.cpu().numpy(), rtol=1e-4, atol=1e-12, err_msg=f"{l.name} ds_b")
+
+
+def test_batched_mode_refuses_silent_gradient_accumulation(dev):
+    import learned_quantization_amd as lq
+    m = _model(dev, "mnist", "rowwise")
+    batch = lq.FakeQuantBatch(m)
+    outs = batch.quantize_all()
+    torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+    outs = batch.quantize_all()
+    with pytest.raises(RuntimeError, match="not supported in batched mode"):
+        torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])

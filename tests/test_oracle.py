@@ -271,3 +271,17 @@ def test_mnist_real_weights_integers(mnist_weights, mnist_expected):
             assert int(q.min()) == m["min"] and int(q.max()) == m["max"]
     # real weights at the init scale: |q| up to ~1.9e4 -- NOT int8-safe
     assert np.abs(exp["W1_q_init"].astype(np.int32)).max() > 127
+
+
+def test_c_oracle_under_asan_ubsan(tmp_path):
+    """The C restatement on ragged shapes under AddressSanitizer + UBSan (CPU build; GPU sanitizers are unavailable)."""
+    import os
+    import subprocess
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    exe = str(tmp_path / "oracle_sanitize")
+    subprocess.check_call(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off",
+                           "-o", exe, os.path.join(root, "tests", "tools", "oracle_sanitize.c"),
+                           os.path.join(root, "oracle", "lq_oracle.c"), "-lm"])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120,
+                         env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1"})
+    assert res.returncode == 0 and "oracle_sanitize: ok" in res.stdout, res.stdout + res.stderr
