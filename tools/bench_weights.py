@@ -49,6 +49,7 @@ def main():
             n_el = sum(e.param.numel() for e in batch.entries)
 
             def batched_step():
+                opt.zero_grad()
                 outs = batch.quantize_all()
                 torch.autograd.backward(outs, dys)
                 opt.step()
