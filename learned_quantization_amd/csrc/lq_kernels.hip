@@ -224,9 +224,14 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         const int grid3d = (p.G <= 65535 && outer_f <= 65535 && pl.R == outer_f * p.G) ? 1 : 0;
         const dim3 grid = grid3d ? dim3((unsigned)pl.nc, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)units);
         const bool nt = vec && (double)pl.R * (double)pl.L * 4.0 >= (double)kNtBytes;
-        // lambda >= 4e-4 (tmode >= 1): two float4 per thread, see row_stream_body.  The unit doubles, so the chunk
-        // count halves; the workspace bound (computed for one float4 per thread) still holds.
-        const bool u2 = (OP == OP_BWD || OP == OP_FUSED) && p.tmode >= 1 && vec && nt && pl.bs == 512;
+        // Two float4 per thread and stream (see row_stream_body): the backward always (measured 100.3 vs 101.4 us per
+        // BENCH step, and 105 vs 116 us at lambda = 1e-3 where every element takes the exact-ratio + tanh branch; it
+        // also halves the partials the finalize walks); the fused kernel only when lambda >= 4e-4 (77.4 vs 81.7 us
+        // there, but 77.7 vs 75.4 us at small lambda).  The unit doubles, so the chunk count halves; the workspace
+        // bound (computed for one float4 per thread) still holds.
+        static const int tune_u2 = getenv("LQ_TUNE_U2") ? atoi(getenv("LQ_TUNE_U2")) : -1;   // development knob: force 0/1
+        const bool want_u2 = tune_u2 >= 0 ? tune_u2 == 1 : (OP == OP_BWD || p.tmode >= 1);
+        const bool u2 = (OP == OP_BWD || OP == OP_FUSED) && want_u2 && vec && nt && pl.bs == 512;
         if (u2) {
             const int64_t nc2 = ceil_div(pl.L, (int64_t)pl.bs * 8);
             const dim3 grid2 = grid3d ? dim3((unsigned)nc2, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)(pl.R * nc2));
