@@ -84,7 +84,8 @@ int lq_fq_scale_grad(const float* P, const float* s, const float* dy, float lamb
                      int64_t outer, int64_t G, int64_t inner, void* stream);
 
 /* ---- K4: forward and NQ backward of one tensor in a single pass (benchmark path) ---
- * Same results as lq_fq_forward followed by lq_fq_scale_grad; P is read once.        */
+ * Same results as lq_fq_forward followed by lq_fq_scale_grad (out, max|q| and the vote count bit for bit; on
+ * streaming-size tensors the vote sum may differ by fp32 summation order, ~1e-7 relative); P is read once.  */
 int lq_fq_fwd_bwd_fused(const float* P, const float* s, const float* dy, float lambda,
                         float* out, float* ds, void* ws, size_t ws_bytes,
                         int64_t outer, int64_t G, int64_t inner, void* stream);

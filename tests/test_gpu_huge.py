@@ -56,7 +56,9 @@ def test_more_than_2_to_31_elements():
     np.testing.assert_allclose(parts[1, 0], mean, rtol=1e-5)
     np.testing.assert_allclose(float(ds), mean * maxq, rtol=1e-5)
     out2, ds2 = lq.fq_fwd_bwd_fused(P, s, dy, lam, out=out)
-    assert torch.equal(ds2, ds)
+    # K4 and K2 may use different unit sizes on streaming-size tensors: max|q| and the count are exact, the vote sum
+    # differs by fp32 summation order only
+    np.testing.assert_allclose(ds2.cpu().numpy(), ds.cpu().numpy(), rtol=1e-6)
     for a, b in ((2 ** 31 - 3000, 2 ** 31 + 3000), (n - 5000, n)):
         _, out_o = O.fq_forward(P[a:b].cpu().numpy(), s.cpu().numpy())
         np.testing.assert_array_equal(out2[a:b].cpu().numpy(), out_o)

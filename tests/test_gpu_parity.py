@@ -217,7 +217,8 @@ def test_bench_shape_full_size_properties(dev):
     for lam in (0.0, 1e-11, 1e-3):
         ds, parts = lq.fq_scale_grad(x, s, dy, lam, return_parts=True)
         out2, ds2 = lq.fq_fwd_bwd_fused(x, s, dy, lam)
-        assert torch.equal(out2, out) and torch.equal(ds2, ds)
+        assert torch.equal(out2, out)
+        np.testing.assert_allclose(ds2.cpu().numpy(), ds.cpu().numpy(), rtol=1e-6)     # unit sizes may differ: summation order only
         # full oracle in float32 NumPy, channel by channel (a few seconds)
         xn, dyn = x.cpu().numpy(), dy.cpu().numpy()
         _, ds_o, im = O.nq_backward(xn, s.cpu().numpy(), lam, dyn, return_intermediates=True)
