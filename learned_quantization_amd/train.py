@@ -156,6 +156,8 @@ def main(argv=None):
     ap.add_argument("--ddp-mode", choices=["A", "B"], default="A")
     ap.add_argument("--export-dir", default=None, help="write the reference's integer export here at the end")
     ap.add_argument("--graph", action="store_true", help="capture the whole step in a hipGraph (single GPU)")
+    ap.add_argument("--backend", default="nccl", help="nccl = RCCL over xGMI (default); gloo + --share-gpu rehearses N>1 on one GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--batched", action="store_true", help="multi-tensor launches for all fake-quant ops of a step (lq_batch_*)")
     args = ap.parse_args(argv)
 
@@ -163,11 +165,18 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("the training harness needs an MI355X (no CPU fallback)")
+    if args.share_gpu:
+        if args.backend == "nccl":
+            raise SystemExit("--share-gpu needs --backend gloo (RCCL cannot put two ranks on one GPU)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     rank = dist.get_rank() if world > 1 else 0
 
     tr = Trainer(args.config, args.mode, args.value, args.orientation, args.loss, seed=args.seed, device=dev,
