@@ -134,3 +134,33 @@ def test_capturable_scale_adam_and_graphed_step(dev, tmp_path):
     assert all(np.isfinite(l) for l in losses) and tr.graph is not None
     s1 = tr.custom_layers[0].nested_q_k_layer.scale.detach()
     assert bool((s1 >= s0).all()) and float(s1.min()) >= O.SCALE_MIN
+
+
+def test_experiment_driver_end_to_end(dev, tmp_path, mnist_weights):
+    """The reference's main() flow on synthetic data: log tree, callbacks, export -- from scratch and post-training (PTQ)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    base = ["--seed", "42", "--epochs", "2", "--steps-per-epoch", "3", "--batch", "16", "--log-root", str(tmp_path)]
+    runs = [["--config", "cifar", "--orientation", "channelwise", "--training", "from_scratch"],
+            ["--config", "cifar", "--orientation", "rowwise", "--training", "from_scratch", "--custom_loss", "difference", "--batched"],
+            ["--config", "mnist", "--orientation", "rowwise", "--training", "post_training", "--value", "1e-10",
+             "--baseline-weights", os.path.join(root, "tests", "golden", "mnist_baseline_weights.npz")]]
+    for extra in runs:
+        res = subprocess.run([sys.executable, "-m", "learned_quantization_amd.experiment"] + base + extra, cwd=root,
+                             capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stdout + res.stderr
+        out = json.loads(res.stdout.strip().splitlines()[-1])
+        d = out["log_dir"]
+        assert f"{extra[3]}_{extra[5]}" in d and "seed_42" in d and "_lr_0.0001_pr_" in d
+        for f in ("model_structure.log", "weights.npy", "weights.zip", "file_sizes.log", "scales.npz",
+                  "accuracy/val_accuracy.log", "loss/train_loss.log"):
+            assert os.path.exists(os.path.join(d, f)), f
+        assert len(os.listdir(os.path.join(d, "on_epoch_end"))) > 0 and len(os.listdir(os.path.join(d, "on_train_end"))) > 0
+        assert open(os.path.join(d, "loss", "val_loss.log")).read().startswith("Epoch 0\n")
+        assert out["export"]["zip_mb"] > 0 and np.isfinite(out["final"]["loss"])
+        if extra[1] == "mnist":
+            # PTQ from the shipped baseline: the first layer's weights really are the baseline's
+            w = np.load(os.path.join(d, "weights.npy"), allow_pickle=True).item()
+            assert w["custom_dense_layer/W"].shape == mnist_weights["W1"].shape
