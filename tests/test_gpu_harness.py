@@ -164,3 +164,39 @@ def test_experiment_driver_end_to_end(dev, tmp_path, mnist_weights):
             # PTQ from the shipped baseline: the first layer's weights really are the baseline's
             w = np.load(os.path.join(d, "weights.npy"), allow_pickle=True).item()
             assert w["custom_dense_layer/W"].shape == mnist_weights["W1"].shape
+
+
+def test_functional_sanity_quantization_emerges_without_accuracy_loss(dev, mnist_weights, tmp_path):
+    """SURVEY 8c item 3 (coarse end-to-end sanity): from the shipped MNIST baseline weights, on a synthetic task labelled
+    by the baseline itself, the nested quantization layer collapses the integer range for lambda > 0 (thesis chapter4.tex:
+    123-127: tens of integers), leaves it untouched for lambda = 0 (no quantisation pressure), and the quantised model
+    tracks the accuracy of the unquantised run."""
+    import learned_quantization_amd as lq
+    from learned_quantization_amd.train import Trainer
+    W1, b1, W2, b2 = (torch.tensor(mnist_weights[k], device=dev) for k in ("W1", "b1", "W2", "b2"))
+
+    def teacher(x):
+        return ((torch.relu(torch.flatten(x, 1) @ W1 + b1)) @ W2 + b2).argmax(1)
+
+    def images(n, g):
+        m = (torch.rand(n, 1, 28, 28, device=dev, generator=g) < 0.19).float()
+        return m * torch.rand(n, 1, 28, 28, device=dev, generator=g)
+
+    results = {}
+    for lam in (0.0, 1e-8):
+        tr = Trainer("mnist", "nq", lam, "rowwise", None, device=dev, seed=42, batched=True, log_dir=str(tmp_path))
+        with torch.no_grad():
+            tr.model.dense_1.W.copy_(W1); tr.model.dense_1.b.copy_(b1); tr.model.dense_2.W.copy_(W2); tr.model.dense_2.b.copy_(b2)
+        g = torch.Generator(device=dev).manual_seed(0)
+        xv = images(2048, g)
+        yv = teacher(xv)
+        _, acc0 = tr.evaluate(xv, yv)
+        assert acc0 > 0.99                                   # floor() at the initial scale 1.19e-5 is nearly lossless
+        for _ in range(600):
+            x = images(32, g)
+            tr.step(x, teacher(x))
+        uniq = int(lq.q_unique(tr.model.dense_1.W.data, tr.model.dense_1.nested_q_w_layer.scale.data)[0].numel())
+        results[lam] = (uniq, tr.evaluate(xv, yv)[1], float(tr.model.dense_1.nested_q_w_layer.scale.min()))
+    assert results[0.0][0] > 10000 and results[0.0][2] == pytest.approx(lq.SCALE_INIT)     # lambda = 0: scales never move
+    assert results[1e-8][0] < 300                                                            # lambda > 0: a few dozen/hundred integers
+    assert abs(results[1e-8][1] - results[0.0][1]) < 0.05                                    # same accuracy as the unquantised run
