@@ -33,7 +33,7 @@ at construction (NQ-L:133-145) are dropped.
 from __future__ import annotations
 
 import math
-from typing import Callable, Optional, Sequence, Tuple, Union
+from typing import Optional, Tuple
 
 import numpy as np
 import torch

@@ -147,7 +147,6 @@ def test_q_dtypes_and_int8_wrap(dev):
 
 def test_edge_empty_and_bad_arguments(dev):
     import learned_quantization_amd as lq
-    from learned_quantization_amd._hip import LQError
     with pytest.raises(ValueError):
         lq.fq_forward(torch.empty(0, device=dev), torch.ones(1, device=dev))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
