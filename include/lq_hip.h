@@ -217,6 +217,10 @@ int lq_q_histogram(const float* P, const float* s, int32_t qmin, int64_t nbins, 
  * number of bit mismatches to *mismatches_dev (uint64 on the device, zeroed by the caller). Expected: 0.   */
 int lq_selftest_ratio_division(uint64_t seed, uint32_t blocks, uint32_t pairs_per_thread, uint64_t* mismatches_dev,
                                void* stream);
+/* The same for the uniform-divisor division of the streaming kernels (r = RN(1/s) + two fma refinements, see
+ * lq_math.hpp): random s in [2^-40, 2^40], random x in [2^-80, 2^81), both signs.  Expected: 0 mismatches.      */
+int lq_selftest_uniform_division(uint64_t seed, uint32_t blocks, uint32_t pairs_per_thread, uint64_t* mismatches_dev,
+                                 void* stream);
 
 #ifdef __cplusplus
 }

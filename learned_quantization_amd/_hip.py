@@ -66,6 +66,7 @@ SIGNATURES.update({
     "lq_batch_scale_adam": (_c_int, [_c_p, _c_d, _c_d, _c_d, _c_d, _c_i64, _c_p, _c_int, _c_p]),
     "lq_batch_penalty_grads": (_c_int, [_c_p, _c_int, ctypes.POINTER(_c_f), ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
     "lq_selftest_ratio_division": (_c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _c_p, _c_p]),
+    "lq_selftest_uniform_division": (_c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _c_p, _c_p]),
     "lq_q_minmax": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "lq_q_histogram": (_c_int, [_c_p, _c_p, ctypes.c_int32, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
 })
@@ -98,7 +99,32 @@ def load() -> ctypes.CDLL:
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = lib
+        _device_selftest(lib)
         return lib
+
+
+_selftested = False
+
+
+def _device_selftest(lib) -> None:
+    """Once per process, on the first load with a GPU present: 2^24 random operand pairs through each of the two fast
+    division forms against the IEEE '/' ON THIS DEVICE.  The bit-exact-integer guarantee rests on them; a compiler
+    or hardware combination that ever disagrees must fail loudly, not quantise differently.  LQ_SKIP_SELFTEST=1 skips."""
+    global _selftested
+    if _selftested or os.environ.get("LQ_SKIP_SELFTEST") == "1" or not torch.cuda.is_available():
+        return
+    _selftested = True
+    if torch.cuda.is_current_stream_capturing():
+        return
+    bad = torch.zeros(2, dtype=torch.int64, device="cuda")
+    rc = lib.lq_selftest_ratio_division(0x5EED, 256, 256, bad.data_ptr(), None)
+    rc |= lib.lq_selftest_uniform_division(0x5EED, 256, 256, bad.data_ptr() + 8, None)
+    torch.cuda.synchronize()
+    n_ratio, n_uniform = (int(v) for v in bad.tolist())
+    if rc or n_ratio or n_uniform:
+        raise RuntimeError(f"learned_quantization_amd: device self-test failed (rc={rc}, ratio division mismatches={n_ratio}, "
+                           f"uniform division mismatches={n_uniform}): the fast division forms do not reproduce IEEE fp32 "
+                           "division on this device/compiler; refusing to run")
 
 
 def check(rc: int, what: str) -> None:

@@ -212,6 +212,32 @@ __global__ __launch_bounds__(kBlock) void k_selftest_ratio_div(uint64_t seed, ui
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// Same for the uniform-divisor division of the streaming kernels: x / s with r = RN(1/s), 2^-40 <= s <= 2^40
+// (mantissa not all ones), 2^-80 <= |x| < 2^81, random signs.
+__global__ __launch_bounds__(kBlock) void k_selftest_uniform_div(uint64_t seed, uint32_t per_thread, unsigned long long* mismatches) {
+    uint64_t x = seed ^ (0xD1B54A32D192ED03ull * ((uint64_t)blockIdx.x * kBlock + threadIdx.x + 1));
+    unsigned long long bad = 0;
+    for (uint32_t k = 0; k < per_thread; ++k) {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        const uint32_t es = 87u + (uint32_t)((x >> 8) % 81u), ex = 47u + (uint32_t)((x >> 24) % 161u);
+        uint32_t ms = (uint32_t)(x >> 40) & 0x7fffffu;
+        const uint32_t mx = (uint32_t)(x * 0x2545F4914F6CDD1Dull >> 41) & 0x7fffffu;
+        if (ms == 0x7fffffu) ms = 0x7ffffeu;
+        if (es == 167u) ms = 0u;
+        Ctx c;
+        c.s = __uint_as_float((es << 23) | ms);
+        div_ctx(c);
+        const float xv = __uint_as_float((uint32_t)((x >> 63) << 31) | (ex << 23) | mx);
+        const float want = xv / c.s;
+        const float got = c.fast ? fast_div(xv, c.s, c.r) : want;
+        bad += (__float_as_uint(want) != __float_as_uint(got)) ? 1ull : 0ull;
+        bad += c.fast ? 0ull : 1ull;      // every generated divisor must be inside the fast window
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace lq
 
 #endif

@@ -895,4 +895,12 @@ int lq_q_histogram(const float* P, const float* s, int32_t qmin, int64_t nbins, 
     return check_hip("q histogram launch");
 }
 
+int lq_selftest_uniform_division(uint64_t seed, uint32_t blocks, uint32_t pairs_per_thread, uint64_t* mismatches_dev, void* stream) {
+    if (!mismatches_dev || !aligned(mismatches_dev, 8)) return fail(LQ_EINVAL, "lq_selftest_uniform_division: mismatches_dev must be an 8-byte aligned device pointer");
+    if (blocks == 0 || pairs_per_thread == 0) return fail(LQ_EINVAL, "lq_selftest_uniform_division: empty test");
+    hipLaunchKernelGGL(k_selftest_uniform_div, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, seed, pairs_per_thread,
+                       reinterpret_cast<unsigned long long*>(mismatches_dev));
+    return check_hip("selftest launch");
+}
+
 }  // extern "C"

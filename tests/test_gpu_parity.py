@@ -260,6 +260,11 @@ def test_window_division_selftest(dev):
         _hip.check(lib.lq_selftest_ratio_division(seed, 8192, 1024, bad.data_ptr(), None), "selftest")
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
+    bad.zero_()
+    for seed in (3, 0xC0FFEE, 99):
+        _hip.check(lib.lq_selftest_uniform_division(seed, 8192, 1024, bad.data_ptr(), None), "selftest")
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
 
 
 @pytest.mark.parametrize("orient", ["rowwise", "columnwise", "scalar"])
