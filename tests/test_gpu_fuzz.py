@@ -168,3 +168,31 @@ def test_pathological_scales(dev):
         _, out3_o = O.fq_forward(np.ascontiguousarray(P2.T), s.reshape(1, 6))
     np.testing.assert_array_equal(lq.fq_forward(_t(P2, dev), _t(s, dev)).cpu().numpy(), out2_o)
     np.testing.assert_array_equal(lq.fq_forward(_t(np.ascontiguousarray(P2.T), dev), _t(s.reshape(1, 6), dev)).cpu().numpy(), out3_o)
+
+
+def test_negative_and_nan_threshold(dev):
+    """penalty_threshold outside its meaningful range still follows the reference's comparisons: lambda < 0 -> every ratio
+    is 'above' -> mean = -|tanh(lambda)|; lambda = NaN -> every comparison is false -> NaN."""
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(8)
+    P = rng.normal(0, 0.05, size=(5, 3000)).astype(np.float32)
+    dy = rng.normal(0, 1e-3, size=P.shape).astype(np.float32)
+    s = rng.uniform(1e-3, 1e-2, size=(5, 1)).astype(np.float32)
+    for lam in (-1e-3, -0.5):
+        with np.errstate(all="ignore"):
+            _, ds_o = O.nq_backward(P, s, lam, dy)
+        ds = lq.fq_scale_grad(_t(P, dev), _t(s, dev), _t(dy, dev), lam).cpu().numpy()
+        np.testing.assert_allclose(ds, ds_o, rtol=RTOL)
+    with np.errstate(all="ignore"):
+        _, ds_o = O.nq_backward(P, s, float("nan"), dy)
+    ds = lq.fq_scale_grad(_t(P, dev), _t(s, dev), _t(dy, dev), float("nan")).cpu().numpy()
+    assert np.all(np.isnan(ds_o)) and np.all(np.isnan(ds))
+
+
+def test_int32_view_saturates(dev):
+    import learned_quantization_amd as lq
+    P = np.array([1e30, -1e30, 2147483520.0, 2147483648.0, -2147483648.0, -2147483904.0, np.nan, np.inf, -np.inf, 5.9], np.float32)
+    s = np.array([1.0], np.float32)
+    q = lq.quantized_integers(_t(P, dev), _t(s, dev), torch.int32).cpu().numpy()
+    i32 = np.iinfo(np.int32)
+    np.testing.assert_array_equal(q, np.array([i32.max, i32.min, 2147483520, i32.max, i32.min, i32.min, 0, i32.max, i32.min, 5], np.int64).astype(np.int32))
