@@ -337,6 +337,29 @@ def main():
             extras[name] = {"images_per_s": BATCH / dt, "us_per_step": dt * 1e6, "step_GBs": nbytes / dt / 1e9,
                             "algorithmic_bytes_per_step": nbytes}
 
+        # BASELINE.json configs[1] end to end (informational; MIOpen convolutions dominate it and are out of scope):
+        # CIFAR-10 small CNN, nested quantization layer, bs 256, multi-tensor batch + whole step in one hipGraph
+        try:
+            from learned_quantization_amd.train import Trainer, synthetic_batch
+            tr = Trainer("cifar", "nq", 1e-11, "channelwise", None, device=dev, seed=42, graph=True, batched=True,
+                         log_dir=os.path.join("/tmp", "lq_bench_logs"))
+            gb = torch.Generator(device=dev).manual_seed(7)
+            bx, by = synthetic_batch("cifar", 256, dev, gb)
+            for _ in range(5):
+                tr.step_graphed(bx, by)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(30):
+                tr.step_graphed(bx, by)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / 30
+            extras["e2e_cifar_cnn_bs256_nq_channelwise_hipgraph_batched"] = {
+                "images_per_s": 256 / dt, "ms_per_step": dt * 1e3, "quantized_elements": 287008,
+                "note": "full training step (MIOpen convs + lq kernels + optimizers), synthetic data"}
+            del tr
+        except Exception as e:      # never let the informational extra break the bench line
+            extras["e2e_cifar_cnn_bs256_nq_channelwise_hipgraph_batched"] = {"error": repr(e)[:200]}
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
