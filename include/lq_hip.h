@@ -200,6 +200,19 @@ typedef enum lq_penalty_kind { LQ_PENALTY_MAXBIN = 0, LQ_PENALTY_DIFFERENCE = 1,
 int lq_batch_penalty_grads(const lq_batch* batch, int kind, const float* coeff, float* const* grad,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* ---- multi-tensor Adam for the ordinary parameters (SURVEY f-4) -------------------------------------------
+ * The reference trains everything with Keras 2.11 Adam(learning_rate=1e-4)
+ *   CIFAR-10/nested_quantization_layer/experiment.py:435-443.
+ * An lq_adam_set holds (w, m, v, n[, min_value]) of up to 256 tensors; lq_adam_set_step applies one Adam step to all of
+ * them in ONE launch with the arithmetic of lq_scale_adam_step (mode LQ_ADAM_KERAS / LQ_ADAM_TORCH); `grads` is a host
+ * array of device pointers (they move every step; a NULL entry skips that tensor), `step_dev` (optional) a device int64 for hipGraph capture.        */
+typedef struct lq_adam_set lq_adam_set;
+int lq_adam_set_create(float* const* w, float* const* m, float* const* v, const int64_t* n, const float* min_value, int count,
+                       lq_adam_set** out);
+int lq_adam_set_destroy(lq_adam_set* set);
+int lq_adam_set_step(const lq_adam_set* set, const float* const* grads, double lr, double beta1, double beta2, double eps,
+                     int64_t step, const int64_t* step_dev, int mode, void* stream);
+
 /* ---- integer-view range and histogram (tracking callbacks) -----------------------------------------
  * The reference's callbacks pull floor(P/s) to the host and run np.unique on it every epoch
  *   CIFAR-10/nested_quantization_layer/custom_components/custom_callbacks.py:85-96, 131-207.

@@ -12,7 +12,7 @@ from .layers import (CustomConv2DLayer, CustomConv2DLayerNoBias, CustomDenseLaye
 from .losses import SCCEDifference, SCCEInverse, SCCEMaxBin, sparse_categorical_crossentropy
 from .ops import (difference_term, fq_forward, fq_fwd_bwd_fused, fq_scale_grad, inverse_term, maxbin_term,
                   my_custom_gradient, q_absmax_over_axis, q_unique, quantized_integers)
-from .optim import ScaleAdam, apply_constraints, non_scale_parameters, scale_parameters
+from .optim import KerasAdam, ScaleAdam, apply_constraints, non_scale_parameters, scale_parameters
 from .ddp import DataParallel, GradBucket
 from .batch import BatchedScaleAdam, FakeQuantBatch
 from .models import CIFARCNN, MNISTDense, ResNet18Like, build_model

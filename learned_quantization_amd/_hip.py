@@ -65,6 +65,10 @@ SIGNATURES.update({
     "lq_batch_scale_grad": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
     "lq_batch_scale_adam": (_c_int, [_c_p, _c_d, _c_d, _c_d, _c_d, _c_i64, _c_p, _c_int, _c_p]),
     "lq_batch_penalty_grads": (_c_int, [_c_p, _c_int, ctypes.POINTER(_c_f), ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
+    "lq_adam_set_create": (_c_int, [ctypes.POINTER(_c_p), ctypes.POINTER(_c_p), ctypes.POINTER(_c_p), ctypes.POINTER(_c_i64),
+                                    ctypes.POINTER(_c_f), _c_int, ctypes.POINTER(_c_p)]),
+    "lq_adam_set_destroy": (_c_int, [_c_p]),
+    "lq_adam_set_step": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_d, _c_d, _c_d, _c_d, _c_i64, _c_p, _c_int, _c_p]),
     "lq_selftest_ratio_division": (_c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _c_p, _c_p]),
     "lq_selftest_uniform_division": (_c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _c_p, _c_p]),
     "lq_q_minmax": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),

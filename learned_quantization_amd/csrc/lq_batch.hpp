@@ -160,6 +160,59 @@ __global__ __launch_bounds__(kBlock) void k_batch_adam(const AdamTask* __restric
     }
 }
 
+// Multi-tensor Adam for arbitrary parameter tensors (SURVEY f-4): one launch for the whole parameter set.  Blocks of
+// 256 threads x 4 elements; a block finds its tensor by binary search over the block prefix; gradients arrive through
+// the kernel-argument pointer pack (autograd re-allocates them every step).
+struct VecTask {
+    float* w;
+    float* m;
+    float* v;
+    int64_t n;
+    float min_value;        // -inf: no projection
+    uint32_t first_block;
+};
+
+__global__ __launch_bounds__(kBlock) void k_multi_adam(const VecTask* __restrict__ tasks, int ntasks, PtrPack grads, float lr, float b1, float b2,
+                                                       double lr_d, double b1_d, double b2_d, float f0, float f1, float eps,
+                                                       const int64_t* step_dev, int64_t step_host, int mode) {
+    int lo = 0, hi = ntasks - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tasks[mid].first_block <= blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const VecTask t = tasks[lo];
+    const float* __restrict__ g = grads.dy[lo];
+    if (!g) return;          // no gradient this step: the tensor is skipped (block-uniform)
+    const int64_t step = step_dev ? step_dev[0] : step_host;
+    float alpha = 0.f, step_size = 0.f, sq_bc2 = 1.f;
+    if (mode == LQ_ADAM_KERAS) {
+        const float b1p = powf(b1, (float)step), b2p = powf(b2, (float)step);
+        alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+    } else {
+        const double bc1 = 1.0 - pow(b1_d, (double)step), bc2 = 1.0 - pow(b2_d, (double)step);
+        step_size = (float)(lr_d / bc1);
+        sq_bc2 = (float)sqrt(bc2);
+    }
+    const int64_t base = (int64_t)(blockIdx.x - t.first_block) * (kBlock * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * kBlock + threadIdx.x;
+        if (i < t.n) {
+            const float gi = g[i];
+            float mi = t.m[i], vi = t.v[i], w = t.w[i];
+            mi = mi + (gi - mi) * f0;
+            vi = vi + (gi * gi - vi) * f1;
+            if (mode == LQ_ADAM_KERAS) w = w - (mi * alpha) / (sqrtf(vi) + eps);
+            else w = w - step_size * (mi / (sqrtf(vi) / sq_bc2 + eps));
+            w = (w < t.min_value) ? t.min_value : w;
+            t.m[i] = mi;
+            t.v[i] = vi;
+            t.w[i] = w;
+        }
+    }
+}
+
 }  // namespace lq
 
 #endif

@@ -903,4 +903,76 @@ int lq_selftest_uniform_division(uint64_t seed, uint32_t blocks, uint32_t pairs_
     return check_hip("selftest launch");
 }
 
+}  // extern "C" (reopened below)
+
+struct lq_adam_set {
+    std::vector<lq::VecTask> h;
+    lq::VecTask* d = nullptr;
+    uint32_t blocks = 0;
+};
+
+extern "C" {
+
+int lq_adam_set_create(float* const* w, float* const* m, float* const* v, const int64_t* n, const float* min_value, int count,
+                       lq_adam_set** out) {
+    if (!w || !m || !v || !n || !out) return fail(LQ_EINVAL, "lq_adam_set_create: NULL argument");
+    if (count <= 0 || count > kBatchMax) return fail(LQ_EINVAL, "lq_adam_set_create: count must be in 1..%d", kBatchMax);
+    lq_adam_set* a = new (std::nothrow) lq_adam_set();
+    if (!a) return fail(LQ_EHIP, "lq_adam_set_create: out of host memory");
+    for (int i = 0; i < count; ++i) {
+        if (!w[i] || !m[i] || !v[i] || n[i] <= 0 || !aligned(w[i], 4) || !aligned(m[i], 4) || !aligned(v[i], 4)) {
+            delete a;
+            return fail(LQ_EINVAL, "lq_adam_set_create: tensor %d has a NULL/misaligned pointer or a non-positive size", i);
+        }
+        VecTask t;
+        t.w = w[i];
+        t.m = m[i];
+        t.v = v[i];
+        t.n = n[i];
+        t.min_value = min_value ? min_value[i] : -INFINITY;
+        t.first_block = a->blocks;
+        const int64_t nb = ceil_div(n[i], (int64_t)kBlock * 4);
+        if ((uint64_t)a->blocks + (uint64_t)nb > 0x7fffffffull) {
+            delete a;
+            return fail(LQ_EINVAL, "lq_adam_set_create: too many blocks");
+        }
+        a->blocks += (uint32_t)nb;
+        a->h.push_back(t);
+    }
+    hipError_t e = hipMalloc(&a->d, a->h.size() * sizeof(VecTask));
+    if (e == hipSuccess) e = hipMemcpy(a->d, a->h.data(), a->h.size() * sizeof(VecTask), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        const int rc = fail(LQ_EHIP, "lq_adam_set_create: %s", hipGetErrorString(e));
+        if (a->d) (void)hipFree(a->d);
+        delete a;
+        return rc;
+    }
+    *out = a;
+    return LQ_OK;
+}
+
+int lq_adam_set_destroy(lq_adam_set* a) {
+    if (!a) return LQ_OK;
+    if (a->d) (void)hipFree(a->d);
+    delete a;
+    return LQ_OK;
+}
+
+int lq_adam_set_step(const lq_adam_set* a, const float* const* grads, double lr, double beta1, double beta2, double eps, int64_t step,
+                     const int64_t* step_dev, int mode, void* stream) {
+    if (!a || !grads) return fail(LQ_EINVAL, "lq_adam_set_step: NULL argument");
+    if (!step_dev && step < 1) return fail(LQ_EINVAL, "lq_adam_set_step: step is 1-based");
+    if (mode != LQ_ADAM_KERAS && mode != LQ_ADAM_TORCH) return fail(LQ_EINVAL, "lq_adam_set_step: bad mode %d", mode);
+    PtrPack pk;
+    memset(&pk, 0, sizeof(pk));
+    for (size_t i = 0; i < a->h.size(); ++i) {
+        if (grads[i] && !aligned(grads[i], 4)) return fail(LQ_EINVAL, "lq_adam_set_step: gradient %zu is misaligned", i);
+        pk.dy[i] = grads[i];     // NULL = no gradient this step: that tensor is skipped
+    }
+    hipLaunchKernelGGL(k_multi_adam, dim3(a->blocks), dim3(kBlock), 0, (hipStream_t)stream, a->d, (int)a->h.size(), pk, (float)lr,
+                       (float)beta1, (float)beta2, lr, beta1, beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, step_dev, step,
+                       mode);
+    return check_hip("multi adam launch");
+}
+
 }  // extern "C"

@@ -34,6 +34,96 @@ def apply_constraints(params_or_module) -> None:
             c.project_(p.data)
 
 
+class KerasAdam(torch.optim.Optimizer):
+    """Adam for ANY fp32 parameters with Keras 2.11 arithmetic (the reference's optimizer,
+    /root/reference/CIFAR-10/nested_quantization_layer/experiment.py:435-443) in ONE launch per <= 256 tensors
+    (``lq_adam_set_step``, SURVEY f-4).  ``mode="torch"`` gives torch.optim.Adam's arithmetic instead.  Parameters
+    carrying an ``lq_constraint`` (the learned scales) are projected in the same launch."""
+
+    _CHUNK = 256
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-7,
+                 mode: str = "keras", capturable: bool = False):
+        if mode not in ("keras", "torch"):
+            raise ValueError("mode must be 'keras' or 'torch'")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, mode=mode))
+        self.capturable = capturable
+        self._step = 0
+        self._step_t = None
+        self._sets = None
+
+    def _build(self):
+        import ctypes
+        from . import _hip
+        lib = _hip.load()
+        self._sets = []
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            for p in ps:
+                _hip.require_device_f32(p.data, "parameter")
+                if not p.data.is_contiguous():
+                    raise ValueError("KerasAdam needs contiguous parameters")
+                st = self.state[p]
+                if "m" not in st:
+                    st["m"] = torch.zeros_like(p.data)
+                    st["v"] = torch.zeros_like(p.data)
+            for k in range(0, len(ps), self._CHUNK):
+                chunk = ps[k:k + self._CHUNK]
+                n = len(chunk)
+                w = (ctypes.c_void_p * n)(*[p.data_ptr() for p in chunk])
+                m = (ctypes.c_void_p * n)(*[self.state[p]["m"].data_ptr() for p in chunk])
+                v = (ctypes.c_void_p * n)(*[self.state[p]["v"].data_ptr() for p in chunk])
+                cnt = (ctypes.c_int64 * n)(*[p.numel() for p in chunk])
+                mv = (ctypes.c_float * n)(*[float(getattr(p, "lq_constraint").min_value) if getattr(p, "lq_constraint", None)
+                                            is not None else float("-inf") for p in chunk])
+                handle = ctypes.c_void_p()
+                _hip.check(lib.lq_adam_set_create(w, m, v, cnt, mv, n, ctypes.byref(handle)), "lq_adam_set_create")
+                self._sets.append((group, chunk, handle, (ctypes.c_void_p * n)(), [p.data_ptr() for p in chunk]))
+
+    def __del__(self):
+        try:
+            from . import _hip
+            lib = _hip.load()
+            for _, _, handle, _, _ in (self._sets or []):
+                lib.lq_adam_set_destroy(handle)
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _hip
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._sets is None:
+            self._build()
+        lib = _hip.load()
+        if self.capturable:
+            if self._step_t is None:
+                self._step_t = torch.zeros(1, dtype=torch.int64, device=self._sets[0][1][0].device)
+            self._step_t += 1
+        else:
+            self._step += 1
+        keep = []
+        for group, chunk, handle, gptrs, ptrs in self._sets:
+            for i, p in enumerate(chunk):
+                if p.data_ptr() != ptrs[i]:
+                    raise RuntimeError("a parameter was re-allocated after the optimizer was built; create a new KerasAdam")
+                g = p.grad
+                if g is None:
+                    gptrs[i] = None
+                else:
+                    g = _hip.require_device_f32(g, "gradient")
+                    keep.append(g)
+                    gptrs[i] = g.data_ptr()
+            b1, b2 = group["betas"]
+            md = {"keras": _hip.LQ_ADAM_KERAS, "torch": _hip.LQ_ADAM_TORCH}[group["mode"]]
+            _hip.check(lib.lq_adam_set_step(handle, gptrs, group["lr"], b1, b2, group["eps"], self._step,
+                                            _hip.ptr(self._step_t), md, _hip.stream_ptr(chunk[0].device)), "lq_adam_set_step")
+        return loss
+
+
 class ScaleAdam(torch.optim.Optimizer):
     """Adam for the learned scales with the MinValueConstraint projection fused (K6)."""
 

@@ -30,7 +30,7 @@ from . import layers as L
 from .ddp import DataParallel
 from .losses import SCCEDifference, SCCEInverse, SCCEMaxBin, sparse_categorical_crossentropy
 from .models import INPUT_SHAPES, build_model
-from .optim import ScaleAdam, non_scale_parameters, scale_parameters
+from .optim import KerasAdam, ScaleAdam, non_scale_parameters, scale_parameters
 
 LOSSES = {"maxbin": SCCEMaxBin, "difference": SCCEDifference, "inverse": SCCEInverse}
 
@@ -63,7 +63,8 @@ class Trainer:
         self.dp = DataParallel(self.model, mode=ddp_mode) if self.world > 1 else None
         if graph and self.world > 1:
             raise ValueError("graph capture of the whole step is single-GPU only (the all-reduce stays eager)")
-        self.opt = torch.optim.Adam(non_scale_parameters(self.model), lr=lr, eps=1e-7, capturable=graph)   # Keras Adam defaults
+        # Keras 2.11 Adam (lr 1e-4, eps 1e-7 outside the bias correction) for every ordinary parameter in one launch
+        self.opt = KerasAdam(non_scale_parameters(self.model), lr=lr, eps=1e-7, capturable=graph)
         self.batch = None
         if batched:
             # one launch for every fake-quant forward, two for every scale gradient, one for every scale update

@@ -195,3 +195,40 @@ def test_q_unique_matches_numpy_unique(dev, shape, orient, smag):
     np.testing.assert_array_equal(vals.cpu().numpy(), u.astype(np.int32))
     np.testing.assert_array_equal(counts.cpu().numpy(), c)
     assert int(counts.sum()) == P.size
+
+
+def test_keras_adam_multi_tensor_matches_restatement(dev):
+    """lq_adam_set_step == oracle.keras_adam_step for a set of odd-sized tensors; a parameter without gradient is skipped;
+    torch mode == torch.optim.Adam."""
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(2)
+    shapes = [(5,), (17, 3), (3, 3, 8, 16), (1,), (1025,), (2048, 7)]
+    ps = [torch.nn.Parameter(torch.tensor(rng.normal(0, 0.05, size=s).astype(np.float32), device=dev)) for s in shapes]
+    ref = [p.detach().cpu().numpy().copy() for p in ps]
+    ms = [np.zeros_like(r) for r in ref]
+    vs = [np.zeros_like(r) for r in ref]
+    opt = lq.KerasAdam(ps, lr=1e-3)
+    for step in range(1, 5):
+        for i, p in enumerate(ps):
+            if i == 3 and step == 2:
+                p.grad = None                      # skipped this step
+                continue
+            g = (rng.normal(0, 1.0, size=shapes[i]) * 10.0 ** rng.integers(-4, 1)).astype(np.float32)
+            p.grad = torch.tensor(g, device=dev)
+            # Keras applies the global iteration count to every variable
+            ref[i], ms[i], vs[i] = O.keras_adam_step(ref[i], g, ms[i], vs[i], step, lr=1e-3)
+        opt.step()
+        for i, p in enumerate(ps):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), ref[i], rtol=3e-6, atol=1e-9, err_msg=f"step {step} tensor {i}")
+    # torch arithmetic
+    pa = [torch.nn.Parameter(torch.tensor(r, device=dev)) for r in ref]
+    pb = [torch.nn.Parameter(torch.tensor(r, device=dev)) for r in ref]
+    oa, ob = lq.KerasAdam(pa, lr=1e-3, eps=1e-8, mode="torch"), torch.optim.Adam(pb, lr=1e-3, eps=1e-8)
+    for step in range(3):
+        for a, b in zip(pa, pb):
+            g = torch.tensor(rng.normal(0, 1e-2, size=tuple(a.shape)).astype(np.float32), device=dev)
+            a.grad, b.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5, atol=1e-8)
