@@ -218,8 +218,8 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
     if (pl.mode == MODE_ROW_BIG) {
         const int64_t units = pl.R * pl.nc;
         if (units > 2147483647ll) return fail(LQ_EINVAL, "too many work units (%lld)", (long long)units);
-        const bool vec = (pl.L % 4 == 0 || pl.R == 1) && aligned(p.P, 16) && (!O::kDy || aligned(p.dy, 16)) &&
-                         (!O::kStore || aligned(p.out, 16));
+        // float4 path: 16-byte aligned bases; rows of any length (a scalar head/tail of <= 3 elements re-aligns each chunk)
+        const bool vec = aligned(p.P, 16) && (!O::kDy || aligned(p.dy, 16)) && (!O::kStore || aligned(p.out, 16));
         const int64_t outer_f = pl.R / p.G;
         const int grid3d = (p.G <= 65535 && outer_f <= 65535 && pl.R == outer_f * p.G) ? 1 : 0;
         const dim3 grid = grid3d ? dim3((unsigned)pl.nc, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)units);
@@ -630,7 +630,7 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, uint32_t& block
     if (pl.mode == MODE_ROW_BIG) {
         blocks = pl.R * pl.nc;
         // float4 path: forward needs P and out 16-byte aligned; backward needs P (dy is checked at every launch)
-        t.vec = ((pl.L % 4 == 0 || pl.R == 1) && aligned(d.P, 16) && (bwd || aligned(d.out, 16))) ? 1 : 0;
+        t.vec = (aligned(d.P, 16) && (bwd || aligned(d.out, 16))) ? 1 : 0;
     } else if (pl.mode == MODE_ROW_SMALL) {
         t.vec = row_small_vec(pl, d.P, nullptr, bwd ? nullptr : d.out) ? 1 : 0;
         if (t.vec) t.lpr_log2 = row_small_lpr_log2_vec(pl.L);

@@ -45,22 +45,29 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
     Acc acc = O::template init<Acc>();
 
     if (VEC == 4) {
-        const int len4 = len >> 2;
+        // Rows whose length is not a multiple of 4 start at any of the 4 phases of a 16-byte line: `head` scalar
+        // elements bring the chunk to the next float4 boundary (the base pointers are 16-B aligned on this path), the
+        // body is float4, up to 3 elements remain as a tail.  head == 0 whenever L % 4 == 0.
+        const int phase = (int)(base & 3);
+        int head = (4 - phase) & 3;
+        if (head > len) head = len;
+        const int64_t vbase = base + head;
+        const int vlen = len - head;
+        const int len4 = vlen >> 2;
         // Issue the streaming loads FIRST (they depend only on the kernel arguments and the block index);
         // the per-group context (scale fetch, reciprocal, thresholds) is computed while they are in flight.
         // Inactive lanes of a partial chunk re-read float4 0 of the chunk instead of branching.
-        // A chunk with fewer than 4 elements (len4 == 0; only the last chunk of a flat row, so ck > 0)
+        // A chunk without a complete float4 (len4 == 0; only the last chunk of a row, so ck > 0)
         // reads the float4 just before it: always in bounds, never used.
-        // U = 2 (two float4 per thread and stream) is used when lambda >= 4e-4: every element then takes the
-        // exact-ratio + tanh branch, a wave's compute phase triples, and one float4 per thread no longer keeps
-        // enough bytes in flight per wave-lifetime to stay HBM-bound.
+        // U = 2 (two float4 per thread and stream): more bytes in flight per wave-lifetime; used by the backward always and
+        // by the fused kernel when lambda >= 4e-4 (every element then takes the exact-ratio + tanh branch).
         int64_t i[U];
         float4 x[U], d[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = u * BS + (int)threadIdx.x;
-            i[u] = base + (int64_t)(j < len4 ? j : 0) * 4;
-            const int64_t il = len4 > 0 ? i[u] : base - 4;
+            i[u] = vbase + (int64_t)(j < len4 ? j : 0) * 4;
+            const int64_t il = len4 > 0 ? i[u] : vbase - 4;
             x[u] = load4<NT>(p.P + il);
             d[u] = x[u];
             if (O::kDy) d[u] = load4<NT>(p.dy + il);
@@ -83,12 +90,13 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
                 if (O::kStore) store4<NT>(p.out + i[u], r);
             }
         }
-        // ragged scalar tail: only a single flat row (G == 1) can have len % 4 != 0 on the vector path
-        const int tail = len & 3;
-        if ((int)threadIdx.x < tail) {
-            const int64_t i = base + (int64_t)len4 * 4 + threadIdx.x;
-            float r = O::elem(p, ctx, i, p.P[i], O::kDy ? p.dy[i] : 0.f, acc);
-            if (O::kStore) p.out[i] = r;
+        // scalar head (threads 0..head-1) and tail (threads 8..8+tail-1): at most 6 elements per chunk
+        const int tail = vlen & 3;
+        const int t = (int)threadIdx.x;
+        if (t < head || (t >= 8 && t - 8 < tail)) {
+            const int64_t ie = t < head ? base + t : vbase + (int64_t)len4 * 4 + (t - 8);
+            float r = O::elem(p, ctx, ie, p.P[ie], O::kDy ? p.dy[ie] : 0.f, acc);
+            if (O::kStore) p.out[ie] = r;
         }
     } else {
         float x[4 * U], d[4 * U];
