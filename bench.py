@@ -276,7 +276,7 @@ def main():
         t_fwd = sum(e[0].elapsed_time(e[1]) for e in events) / nev * 1e-3
         t_bwd = sum(e[1].elapsed_time(e[2]) for e in events) / nev * 1e-3
         # Dominant kernel by rocprofv3 (profiles/r01/rocprofv3_kernel_stats_prof_split.csv): K1 k_row_stream<OP_FWD>
-        # (50.2 us) > K2 k_row_stream<OP_BWD> (46.0 us) > K3 k_finalize_block (4.8 us).  K1 is one launch per ABI
+        # (48.8 us) >= K2 k_row_stream<OP_BWD> (48.5 us) > K3 k_finalize_block (4.9 us).  K1 is one launch per ABI
         # call, so the event pair brackets exactly that kernel; the K2+K3 call time is reported beside it.
         kname, kbytes, kt = "k_row_stream<OP_FWD, 4, 512, nt>", BYTES_FWD, t_fwd
         step_bytes = BYTES_FWD + BYTES_BWD
