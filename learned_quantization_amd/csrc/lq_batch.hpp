@@ -81,7 +81,8 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
         if (t.vec) row_small_body<OP, 4>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
         else row_small_body<OP, 1>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
     } else {
-        col_body<OP>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b);
+        __shared__ Acc col_lds[OpT<OP>::kReduce ? kBlock * 4 : 1];
+        col_body<OP, false>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b, t.n1, col_lds);
     }
 }
 

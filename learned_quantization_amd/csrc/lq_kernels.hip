@@ -59,6 +59,7 @@ struct Plan {
     int64_t nc;
     int lpr_log2;
     int64_t C, rps, ysplit;   // column mode
+    int per4;           // column mode, C <= 64: geometry admits the float4 grid-stride variant (ysplit % C == 0)
     int64_t np;         // number of partial triples
     // finalize geometry (per group)
     int64_t gstride, n1, stride1, n2;
@@ -85,20 +86,30 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
             const int64_t C = G * inner;
             // rows per block: ~16 K elements per block for narrow matrices, 128 rows for wide ones
             int64_t RB;
-            if (C <= 64) {
+            int64_t nby = 0;
+            int per4 = 0;
+            if (C <= 64 && (double)outer * (double)C >= (double)kPeriodic4Min) {
+                per4 = 1;
+                // streaming size: a block count that is a multiple of C (what the float4 grid-stride variant needs);
+                // the scalar periodic variant runs on the same geometry (trailing blocks may own no rows)
+                nby = C * ((2048 + C / 2) / C);
+                const int64_t k = 64 / C;
+                RB = ceil_div(ceil_div(outer, nby), 4 * k) * 4 * k;
+            } else if (C <= 64) {
                 const int64_t k = 64 / C;
                 RB = ceil_div(ceil_div(16384, C), 4 * k) * 4 * k;
             } else {
                 RB = 128;
             }
             if (RB > outer) RB = outer;
-            const int64_t nby = ceil_div(outer, RB);
+            if (!nby) nby = ceil_div(outer, RB);
             if (nby * C <= R) {
                 col = true;
                 pl.mode = MODE_COL;
                 pl.C = C;
                 pl.rps = RB;
                 pl.ysplit = nby;
+                pl.per4 = per4;
                 pl.np = nby * C;
                 pl.gstride = inner;
                 pl.n1 = nby;
@@ -199,9 +210,12 @@ static bool row_small_vec(const Plan& pl, const void* P, const void* dy, const v
 }
 
 // column-mode kernel variant and blocks along the columns: 0 = periodic (C <= 64), 4 = float4 tile, 1 = scalar tile
-static void col_variant(const Plan& pl, const void* P, const void* dy, const void* out, int& variant, int64_t& nbx) {
+static void col_variant(const Plan& pl, const void* P, const void* dy, const void* out, int& variant, int64_t& nbx,
+                        bool allow_periodic4 = true) {
+    const bool al16 = aligned(P, 16) && (!dy || aligned(dy, 16)) && (!out || aligned(out, 16));
+    const double bytes = (double)pl.C * (double)pl.ysplit * (double)pl.rps * 4.0;
     if (pl.C <= 64) {
-        variant = 0;
+        variant = (allow_periodic4 && pl.per4 && al16) ? (bytes >= (double)kNtBytes ? 7 : 6) : 0;
         nbx = 1;
     } else if (pl.C % 4 == 0 && aligned(P, 16) && (!dy || aligned(dy, 16)) && (!out || aligned(out, 16))) {
         variant = ((double)pl.C * (double)pl.ysplit * (double)pl.rps * 4.0 >= (double)kNtBytes) ? 5 : 4;
@@ -277,7 +291,7 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         col_variant(pl, p.P, O::kDy ? p.dy : nullptr, O::kStore ? p.out : nullptr, variant, nbx);
         const int64_t blocks = nbx * pl.ysplit;
         if (blocks > 2147483647ll) return fail(LQ_EINVAL, "too many blocks (%lld)", (long long)blocks);
-        hipLaunchKernelGGL((k_col<OP>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.C, pl.rps, nbx, variant);
+        hipLaunchKernelGGL((k_col<OP>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.C, pl.rps, nbx, variant, pl.ysplit);
     }
     return check_hip("traversal launch");
 }
@@ -625,7 +639,7 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, uint32_t& block
     t.C = pl.C;
     t.rps = pl.rps;
     t.nbx = 0;
-    if (pl.mode == MODE_COL) col_variant(pl, d.P, nullptr, bwd ? nullptr : d.out, t.col_variant, t.nbx);
+    if (pl.mode == MODE_COL) col_variant(pl, d.P, nullptr, bwd ? nullptr : d.out, t.col_variant, t.nbx, false);
     int64_t blocks;
     if (pl.mode == MODE_ROW_BIG) {
         blocks = pl.R * pl.nc;

@@ -206,6 +206,72 @@ __device__ __forceinline__ void nq_accumulate4(const float4& q, const float4& o,
     }
 }
 
+// ---- float4 whose four elements belong to four different groups (column traversals): the same branch-light
+// forms with one context and one accumulator per element.
+__device__ __forceinline__ void fq_core4c(const float4& x, const Ctx* c, float4& q, float4& o) {
+    const float amax = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+    const float amin = fminf(fminf(fabsf(x.x), fabsf(x.y)), fminf(fabsf(x.z), fabsf(x.w)));
+    const int fast = c[0].fast & c[1].fast & c[2].fast & c[3].fast;
+    float4 t;
+    if (__builtin_expect((fast != 0) & (amin >= 8.271806125530277e-25f) & (amax < 2.4178516392292583e+24f), 1)) {
+        t.x = fast_div(x.x, c[0].s, c[0].r);
+        t.y = fast_div(x.y, c[1].s, c[1].r);
+        t.z = fast_div(x.z, c[2].s, c[2].r);
+        t.w = fast_div(x.w, c[3].s, c[3].r);
+    } else {
+        t.x = x.x / c[0].s;
+        t.y = x.y / c[1].s;
+        t.z = x.z / c[2].s;
+        t.w = x.w / c[3].s;
+    }
+    q.x = floorf(t.x); q.y = floorf(t.y); q.z = floorf(t.z); q.w = floorf(t.w);
+    o.x = q.x * c[0].s; o.y = q.y * c[1].s; o.z = q.z * c[2].s; o.w = q.w * c[3].s;
+}
+
+template <int TM>
+__device__ __forceinline__ void vote_cast4c(const float4& dy, float b0, float b1, float b2, float b3, float lam, Acc* acc) {
+    const float a0 = fabsf(dy.x), a1 = fabsf(dy.y), a2 = fabsf(dy.z), a3 = fabsf(dy.w);
+    const float lo = fminf(fminf(fminf(a0, a1), fminf(a2, a3)), fminf(fminf(b0, b1), fminf(b2, b3)));
+    const float hi = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
+    const float nan_probe = (a0 + a1) + (a2 + a3) + ((b0 + b1) + (b2 + b3));
+    float r0, r1, r2, r3;
+    if ((lo >= kWinLo) & (hi <= kWinHi) & (nan_probe == nan_probe)) {
+        r0 = window_div(a0, b0);
+        r1 = window_div(a1, b1);
+        r2 = window_div(a2, b2);
+        r3 = window_div(a3, b3);
+    } else {
+        r0 = a0 / b0;
+        r1 = a1 / b1;
+        r2 = a2 / b2;
+        r3 = a3 / b3;
+    }
+    vote_tally<TM>(r0, lam, acc[0]);
+    vote_tally<TM>(r1, lam, acc[1]);
+    vote_tally<TM>(r2, lam, acc[2]);
+    vote_tally<TM>(r3, lam, acc[3]);
+}
+
+__device__ __forceinline__ void nq_accumulate4c(const float4& q, const float4& o, const float4& dy, const Ctx* c, float lam,
+                                                int tmode, Acc* acc) {
+    acc[0].a = __float_as_uint(fmaxf(__uint_as_float(acc[0].a), fabsf(q.x)));
+    acc[1].a = __float_as_uint(fmaxf(__uint_as_float(acc[1].a), fabsf(q.y)));
+    acc[2].a = __float_as_uint(fmaxf(__uint_as_float(acc[2].a), fabsf(q.z)));
+    acc[3].a = __float_as_uint(fmaxf(__uint_as_float(acc[3].a), fabsf(q.w)));
+    const float b0 = (o.x == 0.0f) ? kEpsF32 : fabsf(o.x);   // :63
+    const float b1 = (o.y == 0.0f) ? kEpsF32 : fabsf(o.y);
+    const float b2 = (o.z == 0.0f) ? kEpsF32 : fabsf(o.z);
+    const float b3 = (o.w == 0.0f) ? kEpsF32 : fabsf(o.w);
+    const float lh = c[0].lam_hi;                             // lambda-only: the same in all four contexts
+    const bool all_sure = ((c[0].sure_ok & c[1].sure_ok & c[2].sure_ok & c[3].sure_ok) != 0) & (fabsf(dy.x) >= lh * b0) &
+                          (fabsf(dy.y) >= lh * b1) & (fabsf(dy.z) >= lh * b2) & (fabsf(dy.w) >= lh * b3);
+    if (!all_sure) {
+        if (tmode == 0) vote_cast4c<0>(dy, b0, b1, b2, b3, lam, acc);
+        else if (tmode == 1) vote_cast4c<1>(dy, b0, b1, b2, b3, lam, acc);
+        else vote_cast4c<2>(dy, b0, b1, b2, b3, lam, acc);
+    }
+}
+
 template <int Q>
 __device__ __forceinline__ void store_q_scalar(void* qp, int64_t i, float q) {
     if (Q == LQ_Q_F32) {

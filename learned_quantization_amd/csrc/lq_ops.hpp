@@ -16,6 +16,7 @@ struct OpT;
 struct OpBase {
     static constexpr bool kStdMerge = true;   // merge is (max, add, add): DPP reduction applies
     static constexpr bool kVec4 = false;      // op provides elem4()
+    static constexpr bool kVec4c = false;     // op provides elem4c(): float4 with one context/accumulator per element
     static constexpr bool kDy = false;
     static constexpr bool kStore = false;
     static constexpr bool kReduce = false;
@@ -65,6 +66,18 @@ struct OpT<OP_FWD> : OpBase {
         }
         return o;
     }
+    static constexpr bool kVec4c = true;
+    __device__ static __forceinline__ float4 elem4c(const Params& p, const Ctx* c, int64_t i, const float4& x, const float4&, Acc*) {
+        float4 q, o;
+        fq_core4c(x, c, q, o);
+        if (p.q) {
+            store_q(p.q, p.q_dtype, i + 0, q.x);
+            store_q(p.q, p.q_dtype, i + 1, q.y);
+            store_q(p.q, p.q_dtype, i + 2, q.z);
+            store_q(p.q, p.q_dtype, i + 3, q.w);
+        }
+        return o;
+    }
 };
 
 template <>
@@ -94,6 +107,13 @@ struct OpT<OP_BWD> : OpBase {
         nq_accumulate4(q, o, dy, c, p.lam, p.tmode, acc);
         return o;
     }
+    static constexpr bool kVec4c = true;
+    __device__ static __forceinline__ float4 elem4c(const Params& p, const Ctx* c, int64_t, const float4& x, const float4& dy, Acc* acc) {
+        float4 q, o;
+        fq_core4c(x, c, q, o);
+        nq_accumulate4c(q, o, dy, c, p.lam, p.tmode, acc);
+        return o;
+    }
 };
 
 template <>
@@ -112,6 +132,13 @@ struct OpT<OP_FUSED> : OpBase {
         float4 q, o;
         fq_core4(x, c, q, o);
         nq_accumulate4(q, o, dy, c, p.lam, p.tmode, acc);
+        return o;
+    }
+    static constexpr bool kVec4c = true;
+    __device__ static __forceinline__ float4 elem4c(const Params& p, const Ctx* c, int64_t, const float4& x, const float4& dy, Acc* acc) {
+        float4 q, o;
+        fq_core4c(x, c, q, o);
+        nq_accumulate4c(q, o, dy, c, p.lam, p.tmode, acc);
         return o;
     }
 };

@@ -219,7 +219,7 @@ __device__ __forceinline__ void col_cross_wave(Acc* lds, const Acc& mine, int sl
 }
 
 template <int OP, int VW, int NT>
-__device__ __forceinline__ void col_tile_body(const Params& p, int64_t C, int64_t RB, int64_t bx, int64_t by) {
+__device__ __forceinline__ void col_tile_body(const Params& p, int64_t C, int64_t RB, int64_t bx, int64_t by, Acc* lds) {
     using O = OpT<OP>;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t col0 = (bx * 64 + lane) * VW;
@@ -256,19 +256,25 @@ __device__ __forceinline__ void col_tile_body(const Params& p, int64_t C, int64_
             for (int u = 0; u < kColUnroll; ++u) {
                 if (r + 4 * u < r1) {
                     const int64_t i = (r + 4 * u) * C + col0;
-                    float o[VW];
+                    if constexpr (VW == 4 && O::kVec4c) {
+                        const float4 xv = make_float4(x[u][0], x[u][1 % VW], x[u][2 % VW], x[u][3 % VW]);
+                        const float4 dv = O::kDy ? make_float4(d[u][0], d[u][1 % VW], d[u][2 % VW], d[u][3 % VW]) : xv;
+                        const float4 ov = O::elem4c(p, ctx, i, xv, dv, acc);
+                        if (O::kStore) store4<NT>(p.out + i, ov);
+                    } else {
+                        float o[VW];
 #pragma unroll
-                    for (int k = 0; k < VW; ++k) o[k] = O::elem(p, ctx[k], i + k, x[u][k], O::kDy ? d[u][k] : 0.f, acc[k]);
-                    if (O::kStore) {
-                        if (VW == 4) store4<NT>(p.out + i, make_float4(o[0], o[1 % VW], o[2 % VW], o[3 % VW]));
-                        else p.out[i] = o[0];
+                        for (int k = 0; k < VW; ++k) o[k] = O::elem(p, ctx[k], i + k, x[u][k], O::kDy ? d[u][k] : 0.f, acc[k]);
+                        if (O::kStore) {
+                            if (VW == 4) store4<NT>(p.out + i, make_float4(o[0], o[1 % VW], o[2 % VW], o[3 % VW]));
+                            else p.out[i] = o[0];
+                        }
                     }
                 }
             }
         }
     }
     if (O::kReduce) {
-        __shared__ Acc lds[4 * 64 * VW];
 #pragma unroll
         for (int k = 0; k < VW; ++k) lds[w * (64 * VW) + lane * VW + k] = acc[k];
         __syncthreads();
@@ -286,7 +292,7 @@ __device__ __forceinline__ void col_tile_body(const Params& p, int64_t C, int64_
 
 // C <= 64: lane -> (row rl = lane / C, column c = lane % C); a wave reads k = 64 / C whole rows per load.
 template <int OP>
-__device__ __forceinline__ void col_small_body(const Params& p, int C, int64_t RB, int64_t by) {
+__device__ __forceinline__ void col_small_body(const Params& p, int C, int64_t RB, int64_t by, Acc* lds) {
     using O = OpT<OP>;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int k = 64 / C;
@@ -318,7 +324,6 @@ __device__ __forceinline__ void col_small_body(const Params& p, int C, int64_t R
         }
     }
     if (O::kReduce) {
-        __shared__ Acc lds[4 * 64];
         lds[threadIdx.x] = acc;
         __syncthreads();
         if ((int)threadIdx.x < C) {
@@ -330,23 +335,113 @@ __device__ __forceinline__ void col_small_body(const Params& p, int C, int64_t R
     }
 }
 
+// C <= 64, streaming sizes: grid-stride over float4 vectors with a thread count T that is a multiple of C.  Thread
+// `tid` sees vectors tid, tid + T, ... whose four columns (4*tid + j) % C never change, so -- as in the tile variant --
+// scales and accumulators stay in registers and every load is a fully coalesced float4.  `nblk` (a multiple of C)
+// blocks; a ragged tail of numel % 4 elements is taken by the thread that would own the next vector.
+template <int OP, int NT>
+__device__ __forceinline__ void col_periodic4_body(const Params& p, int C, int64_t nblk, int64_t blk, Acc* lds) {
+    using O = OpT<OP>;
+    constexpr int kPerU = O::kDy ? 2 : 4;      // float4 per stream in flight (measured: one stream wants 4, two streams 2)
+    const int64_t numel = p.outer * (int64_t)C;
+    const int64_t T = nblk * kBlock;
+    const int64_t tid = blk * kBlock + threadIdx.x;
+    const int c0 = (int)((tid * 4) % C);
+    Ctx ctx[4];
+    Acc acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc[j] = O::template init<Acc>();
+        ctx[j] = O::ctx(p, ((c0 + j) % C) / p.inner);
+    }
+    const int64_t nv = numel >> 2;
+    for (int64_t v = tid; v < nv; v += T * kPerU) {
+        float4 x[kPerU], d[kPerU];
+#pragma unroll
+        for (int u = 0; u < kPerU; ++u) {
+            const int64_t vv = (v + u * T < nv) ? v + u * T : v;          // clamp: loads stay unconditional
+            x[u] = load4<NT>(p.P + vv * 4);
+            d[u] = x[u];
+            if (O::kDy) d[u] = load4<NT>(p.dy + vv * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < kPerU; ++u) {
+            if (v + u * T < nv) {
+                const int64_t i = (v + u * T) * 4;
+                float4 o;
+                if constexpr (O::kVec4c) {
+                    o = O::elem4c(p, ctx, i, x[u], d[u], acc);
+                } else {
+                    o.x = O::elem(p, ctx[0], i + 0, x[u].x, d[u].x, acc[0]);
+                    o.y = O::elem(p, ctx[1], i + 1, x[u].y, d[u].y, acc[1]);
+                    o.z = O::elem(p, ctx[2], i + 2, x[u].z, d[u].z, acc[2]);
+                    o.w = O::elem(p, ctx[3], i + 3, x[u].w, d[u].w, acc[3]);
+                }
+                if (O::kStore) store4<NT>(p.out + i, o);
+            }
+        }
+    }
+    const int rem = (int)(numel & 3);
+    if (rem && tid == nv % T) {
+        const int64_t i = nv * 4;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j < rem) {
+                const float o = O::elem(p, ctx[j], i + j, p.P[i + j], O::kDy ? p.dy[i + j] : 0.f, acc[j]);
+                if (O::kStore) p.out[i + j] = o;
+            }
+        }
+    }
+    if (O::kReduce) {
+        Acc* lds2 = lds + kBlock * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[threadIdx.x * 4 + j] = acc[j];
+        __syncthreads();
+        // entry e of this block belongs to column (blk*1024 + e) % C; H helpers per column walk them in a fixed order
+        const int H = kBlock / C;
+        const int c = (int)threadIdx.x % C, h = (int)threadIdx.x / C;
+        const int b0 = (int)((blk * (kBlock * 4)) % C);
+        if (h < H) {
+            int e0 = c - b0;
+            if (e0 < 0) e0 += C;
+            Acc r = O::template init<Acc>();
+            for (int e = e0 + h * C; e < kBlock * 4; e += H * C) O::merge(r, lds[e]);
+            lds2[h * C + c] = r;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            Acc r = lds2[threadIdx.x];
+            for (int hh = 1; hh < H; ++hh) O::merge(r, lds2[hh * C + (int)threadIdx.x]);                  // fixed order
+            write_partial(p, blk * C + threadIdx.x, r);
+        }
+    }
+}
+
 // variant: 0 = periodic (C <= 64), 1 = tile with scalar columns, 4 = tile with float4 (4 columns per lane),
-// 5 = float4 tile with nontemporal accesses (tensors >= 64 MiB)
-template <int OP>
-__device__ __forceinline__ void col_body(const Params& p, int64_t C, int64_t RB, int64_t nbx, int variant, int64_t b) {
+// 5 = float4 tile with nontemporal accesses (tensors >= 64 MiB), 6 / 7 = periodic float4 grid-stride (7: nontemporal)
+// One LDS scratch for whichever variant runs (the variants are all inlined into one kernel: private static arrays
+// would add up -- 61 KB per block, two blocks per CU -- instead of overlaying).
+constexpr int kColLdsAcc = kBlock * 5;
+template <int OP, bool P4 = true>      // P4 = false (multi-tensor batches): variants 6 / 7 compiled out, scratch of kBlock*4
+__device__ __forceinline__ void col_body(const Params& p, int64_t C, int64_t RB, int64_t nbx, int variant, int64_t b, int64_t nby, Acc* lds) {
     if (variant == 0) {
-        col_small_body<OP>(p, (int)C, RB, b);
+        col_small_body<OP>(p, (int)C, RB, b, lds);
+    } else if (P4 && variant == 6) {
+        if constexpr (P4) col_periodic4_body<OP, 0>(p, (int)C, nby, b, lds);
+    } else if (P4 && variant == 7) {
+        if constexpr (P4) col_periodic4_body<OP, 1>(p, (int)C, nby, b, lds);
     } else {
         const int64_t by = b / nbx, bx = b - by * nbx;
-        if (variant == 5) col_tile_body<OP, 4, 1>(p, C, RB, bx, by);
-        else if (variant == 4) col_tile_body<OP, 4, 0>(p, C, RB, bx, by);
-        else col_tile_body<OP, 1, 0>(p, C, RB, bx, by);
+        if (variant == 5) col_tile_body<OP, 4, 1>(p, C, RB, bx, by, lds);
+        else if (variant == 4) col_tile_body<OP, 4, 0>(p, C, RB, bx, by, lds);
+        else col_tile_body<OP, 1, 0>(p, C, RB, bx, by, lds);
     }
 }
 
 template <int OP>
-__global__ __launch_bounds__(kBlock) void k_col(Params p, int64_t C, int64_t RB, int64_t nbx, int variant) {
-    col_body<OP>(p, C, RB, nbx, variant, (int64_t)blockIdx.x);
+__global__ __launch_bounds__(kBlock) void k_col(Params p, int64_t C, int64_t RB, int64_t nbx, int variant, int64_t nby) {
+    __shared__ Acc lds[OpT<OP>::kReduce ? kColLdsAcc : 1];
+    col_body<OP>(p, C, RB, nbx, variant, (int64_t)blockIdx.x, nby, lds);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -170,7 +170,13 @@ def nq_backward(parameter, scale, penalty_threshold, dy, return_intermediates=Fa
             count = 1
             for a in axes:
                 count *= parameter.shape[a]
-            reduced = (np.sum(sg, axis=axes, dtype=F32) / F32(count)).astype(F32)  # :113
+            # pairwise float32 summation needs the reduced axes contiguous and last: np.sum over a leading axis of a
+            # C-ordered array accumulates row after row (error ~ N*eps, 2e-3 at N = 350 k), which is not a property
+            # of the reference (TF's reduction order is unspecified) but of that NumPy loop
+            kept = [i for i in range(scale.ndim) if scale.shape[i] != 1]
+            sg_g = np.ascontiguousarray(np.moveaxis(sg, kept, list(range(len(kept)))))
+            sg_g = sg_g.reshape(tuple(parameter.shape[i] for i in kept) + (-1,))
+            reduced = (np.sum(sg_g, axis=-1, dtype=F32) / F32(count)).astype(F32)  # :113
             reduced = reduced.reshape(scale.shape)                               # :114
 
         ds = (reduced * maxvalue).astype(F32)                      # :116

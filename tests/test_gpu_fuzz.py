@@ -96,6 +96,54 @@ def test_fuzz_misaligned_views(dev):
         np.testing.assert_array_equal(out2.cpu().numpy(), out_o)
 
 
+def test_periodic_columns_misaligned_and_penalties(dev):
+    """C <= 64 at streaming size: the float4 grid-stride variant, its scalar fallback on the same geometry (bases off the
+    16-byte grid), and the penalty passes, all against the oracle."""
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(11)
+    for rows, C, inner in ((350001, 3, 1), (90000, 12, 4), (20000, 64, 1)):
+        n = rows * C
+        G = C // inner
+        for off in (0, 1):
+            base_p = torch.from_numpy(rng.normal(0, 0.05, size=n + off).astype(np.float32)).to(dev)
+            base_d = torch.from_numpy(rng.normal(0, 1e-3, size=n + off).astype(np.float32)).to(dev)
+            P, dy = base_p[off:].view(rows, G, inner), base_d[off:].view(rows, G, inner)
+            assert (P.data_ptr() % 16 != 0) == bool(off)
+            s = torch.from_numpy(rng.uniform(1e-3, 1e-2, size=(1, G, 1)).astype(np.float32)).to(dev)
+            Pn, sn, dn = P.cpu().numpy(), s.cpu().numpy(), dy.cpu().numpy()
+            q_o, out_o = O.fq_forward(Pn, sn)
+            tag = f"rows={rows} C={C} inner={inner} off={off}"
+            out, q = lq.fq_forward(P, s, q_dtype=torch.int32)
+            np.testing.assert_array_equal(out.cpu().numpy(), out_o, err_msg=tag)
+            np.testing.assert_array_equal(q.cpu().numpy(), q_o.astype(np.int32), err_msg=tag)
+            for lam in (1e-10, 2e-2):
+                _, ds_o = O.nq_backward(Pn, sn, lam, dn)
+                ds = lq.fq_scale_grad(P, s, dy, lam)
+                np.testing.assert_allclose(ds.cpu().numpy(), ds_o, rtol=RTOL, err_msg=tag)
+                out2, ds2 = lq.fq_fwd_bwd_fused(P, s, dy, lam)
+                np.testing.assert_array_equal(out2.cpu().numpy(), out_o, err_msg=tag)
+                np.testing.assert_array_equal(ds2.cpu().numpy(), ds.cpu().numpy(), err_msg=tag)
+        # penalty terms on the aligned tensor (forward value vs the f64 oracle, gradients vs the f32 oracle)
+        from oracle import lq_oracle_f64 as O64
+        desc = O.group_descriptor(Pn.shape, sn.shape)
+        Pt = P.detach().clone().requires_grad_(True)
+        st = s.detach().clone().requires_grad_(True)
+        mb = lq.maxbin_term(Pt, st)
+        assert float(mb) == pytest.approx(O64.maxbin_term(Pn, sn, *desc), rel=2e-5), tag
+        df = lq.difference_term(Pt, st)
+        assert float(df) == pytest.approx(O64.difference_term(Pn, sn, *desc), rel=2e-5), tag
+        (mb * 0.3).backward()
+        dp, ds_ = O.maxbin_term_grads(Pn, sn, 0.3)
+        np.testing.assert_allclose(Pt.grad.cpu().numpy(), dp, rtol=1e-5, atol=1e-30, err_msg=tag)
+        np.testing.assert_allclose(st.grad.cpu().numpy(), ds_, rtol=1e-4, atol=1e-30, err_msg=tag)
+        Pt.grad = None
+        st.grad = None
+        (df * 0.7).backward()
+        dp, ds_ = O.difference_term_grads(Pn, sn, 0.7)
+        np.testing.assert_allclose(Pt.grad.cpu().numpy(), dp, rtol=1e-5, atol=1e-30, err_msg=tag)
+        np.testing.assert_allclose(st.grad.cpu().numpy(), ds_, rtol=2e-3, atol=np.abs(ds_).max() * 1e-4 + 1e-30, err_msg=tag)
+
+
 def test_fuzz_penalty_terms(dev):
     import learned_quantization_amd as lq
     from oracle import lq_oracle_f64 as O64
