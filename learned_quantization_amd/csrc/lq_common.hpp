@@ -11,7 +11,9 @@ namespace lq {
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr float kEpsF32 = 1.1920928955078125e-07f;   // np.finfo(np.float32).eps, custom_layers.py:11
-constexpr int64_t kPeriodic4Min = 1ll << 20;         // column mode, C <= 64: elements from which the float4 grid-stride variant is used
+constexpr int64_t kPeriodic4Min = 4ll << 20;         // column mode, C <= 64: elements from which the float4 grid-stride variant is used
+                                                     // (the same 4 M boundary as the 512-thread streaming units: below it single-tensor
+                                                     // and batched launches share one geometry and give bit-identical results)
 constexpr int64_t kNtBytes = 64ll << 20;             // tensors at least this large are streamed with nontemporal accesses
 
 // ------------------------------------------------------------------------------------------

@@ -101,7 +101,7 @@ def test_periodic_columns_misaligned_and_penalties(dev):
     16-byte grid), and the penalty passes, all against the oracle."""
     import learned_quantization_amd as lq
     rng = np.random.default_rng(11)
-    for rows, C, inner in ((350001, 3, 1), (90000, 12, 4), (20000, 64, 1)):
+    for rows, C, inner in ((1400001, 3, 1), (350000, 12, 4), (66000, 64, 1), (350001, 3, 1)):   # the last: below 4 M, scalar form
         n = rows * C
         G = C // inner
         for off in (0, 1):

@@ -85,10 +85,10 @@ SHAPES = [
     ((50, 9), "rowwise"),              # tiny rows (lanes-per-row = 4)
     ((6, 1), "rowwise"),               # L = 1
     ((4, 3, 16, 16), "columnwise"),    # NCHW per-channel, small
-    ((349527, 3), "columnwise"),       # column mode C = 3 at streaming size: float4 grid-stride variant, numel % 4 == 1
-    ((40000, 4, 8), "columnwise"),     # C = 32 (G = 4, inner = 8)
-    ((21001, 7, 9), "columnwise"),     # C = 63, numel % 4 == 3
-    ((300000, 5), "columnwise"),       # C = 5
+    ((1398103, 3), "columnwise"),      # column mode C = 3 at streaming size (>= 4 M): float4 grid-stride variant, numel % 4 == 1
+    ((140000, 4, 8), "columnwise"),    # C = 32 (G = 4, inner = 8)
+    ((66601, 7, 9), "columnwise"),     # C = 63, numel % 4 == 3
+    ((840000, 5), "columnwise"),       # C = 5
 ]
 
 
