@@ -29,7 +29,7 @@ CASES = [
 ]
 
 
-def timed(fn, n=20):
+def timed(fn, n=60):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -40,6 +40,9 @@ def timed(fn, n=20):
     return (time.perf_counter() - t0) / n
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "fill":
+    # chunk-fill probe: rows of 12 / 12.25 / 12.5 / 13 chunks of 4096 elements
+    CASES = [(f"fill probe (256, 3, {L})", (256, 3, L)) for L in (49152, 50176, 51200, 53248, 50176)]
 for name, (outer, G, inner) in CASES:
     n = outer * G * inner
     sets = []
