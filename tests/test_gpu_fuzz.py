@@ -6,8 +6,13 @@ import torch
 
 from oracle import lq_oracle as O
 
+import os
+
 pytestmark = pytest.mark.gpu
 RTOL = 1e-5
+# tools/soak_fuzz.py re-runs these sweeps with other seeds / more cases in one process
+SEED_SHIFT = int(os.environ.get("LQ_FUZZ_SEED", "0"))
+ITER_SCALE = int(os.environ.get("LQ_FUZZ_SCALE", "1"))
 
 
 @pytest.fixture(scope="module")
@@ -58,8 +63,8 @@ def _t(a, dev):
 
 def test_fuzz_forward_backward(dev):
     import learned_quantization_amd as lq
-    rng = np.random.default_rng(20240229)
-    for it in range(160):
+    rng = np.random.default_rng(20240229 + SEED_SHIFT)
+    for it in range(160 * ITER_SCALE):
         P, s, dy, lam, orient = _rand_case(rng)
         tag = f"case {it}: shape={P.shape} orient={orient} lam={lam}"
         with np.errstate(all="ignore"):
@@ -79,8 +84,8 @@ def test_fuzz_forward_backward(dev):
 def test_fuzz_misaligned_views(dev):
     """Storage offsets of 1..3 floats break 16-byte alignment: the scalar kernels must give identical results."""
     import learned_quantization_amd as lq
-    rng = np.random.default_rng(7)
-    for it in range(24):
+    rng = np.random.default_rng(7 + SEED_SHIFT)
+    for it in range(24 * ITER_SCALE):
         rows, cols = int(rng.integers(1, 6)), int(rng.integers(1024, 6000))
         off = int(rng.integers(1, 4))
         base_p = torch.from_numpy(rng.normal(0, 0.05, size=rows * cols + off).astype(np.float32)).to(dev)
@@ -147,8 +152,8 @@ def test_periodic_columns_misaligned_and_penalties(dev):
 def test_fuzz_penalty_terms(dev):
     import learned_quantization_amd as lq
     from oracle import lq_oracle_f64 as O64
-    rng = np.random.default_rng(99)
-    for it in range(60):
+    rng = np.random.default_rng(99 + SEED_SHIFT)
+    for it in range(60 * ITER_SCALE):
         P, s, _, _, orient = _rand_case(rng)
         s = np.abs(s) + np.float32(1e-12)
         desc = O.group_descriptor(P.shape, s.shape)
