@@ -394,7 +394,11 @@ def main():
                        "step_GBs": step_bytes / (elapsed / args.steps) / 1e9},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_us": kt * 1e6, **extra},
+                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_us": kt * 1e6, **extra,
+                         # math-free kernels of the same shape on this device class (profiles/r01_membench.txt): what a
+                         # streaming kernel can reach of the 8 TB/s spec peak
+                         "stream_ceiling_GBs": {"read1_write1": 6579, "read2": 6808, "read2_write1": 6507,
+                                                "source": "profiles/r01_membench.txt"}},
         }
         if world == 1 and not args.no_extras and not args.graph:
             line["extras"] = extras
