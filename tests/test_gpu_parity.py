@@ -102,6 +102,24 @@ def test_random_parity_all_modes(shape, orient, dev):
         _check_case(P, s, dy, lam, dev, f"{shape} {orient} lam={lam}")
 
 
+RESNET18_KERNELS = [(7, 7, 3, 64), (3, 3, 64, 64), (3, 3, 64, 128), (3, 3, 128, 128), (1, 1, 64, 128), (3, 3, 128, 256),
+                    (3, 3, 256, 256), (1, 1, 128, 256), (3, 3, 256, 512), (3, 3, 512, 512), (1, 1, 256, 512)]
+
+
+@pytest.mark.parametrize("orient", ["rowwise", "columnwise", "channelwise", "scalar"])
+def test_resnet18_kernel_shapes_full_size(orient, dev):
+    """BASELINE configs[2] at full size: every distinct conv kernel of the ResNet-18-like topology (HWIO,
+    IMAGENETTE/nested_quantization_layer/experiment.py:627-760), each orientation, trained-like and initial scales."""
+    rng = np.random.default_rng(1234)
+    for shape in RESNET18_KERNELS:
+        P = rng.normal(0, 0.05, size=shape).astype(np.float32)
+        dy = rng.normal(0, 1e-3, size=shape).astype(np.float32)
+        sshape = O.scale_shape(shape, orient)
+        for s, lam in ((rng.uniform(1e-3, 3e-2, size=sshape).astype(np.float32), 3e-2),
+                       (np.full(sshape, O.SCALE_MIN, np.float32), 1e-11)):
+            _check_case(P, s, dy, lam, dev, f"{shape} {orient} lam={lam}")
+
+
 def test_init_scale_large_integers(dev):
     """s = 100*eps: |q| ~ 2e4, the regime where reciprocal-multiply differs (SURVEY section 7 hard part 1)."""
     rng = np.random.default_rng(1)
