@@ -129,6 +129,19 @@ __global__ __launch_bounds__(BS) void k_one(const float* A, const float* B, floa
     else if (a.x + a.y + a.z + a.w == 123.456f) sink[0] = a.x;
 }
 
+// XCD-aware variant of k_one: workgroup w runs on XCD w % 8 (round-robin dispatch); XMAP 1 gives every XCD one contiguous
+// eighth of the buffer (logical block = (w % 8) * (nb / 8) + w / 8) instead of every eighth block.
+template <int MODE, int BS, int NT, int XMAP>
+__global__ __launch_bounds__(BS) void k_one_x(const float* A, const float* B, float* C, float* sink, int nb) {
+    int w = blockIdx.x;
+    if (XMAP) { const int per = nb >> 3; w = (w & 7) * per + (w >> 3); }
+    const int64_t j = (int64_t)w * BS + threadIdx.x;
+    float4 a = ld<NT>((const float4*)A + j), b;
+    if (MODE == 1 || MODE == 3) { b = ld<NT>((const float4*)B + j); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    if (MODE >= 2) st<NT>((float4*)C + j, a);
+    else if (a.x + a.y + a.z + a.w == 123.456f) sink[0] = a.x;
+}
+
 int main(int argc, char** argv) {
     const int64_t N = 256ll * 3 * 224 * 224;
     const int SETS = 4;
@@ -163,6 +176,13 @@ int main(int argc, char** argv) {
     TB("read2", 1, b2, 256) TB("read2", 1, b2, 512) TB("read2", 1, b2, 1024)
     TB("read1+write1", 2, b2, 256) TB("read1+write1", 2, b2, 512) TB("read1+write1", 2, b2, 1024)
     TB("read2+write1", 3, b3, 256) TB("read2+write1", 3, b3, 512) TB("read2+write1", 3, b3, 1024)
+    }
+    for (int rep = 0; rep < 2; ++rep) {     // nb = N/4/512 = 18816 is a multiple of 8
+        const int nb = (int)(N / 4 / 512);
+        run("xcd round-robin  BS512 read1+write1 nt", b2, [&](int k){ hipLaunchKernelGGL((k_one_x<2, 512, 1, 0>), dim3(nb), dim3(512), 0, 0, A[k], B[k], C[k], sink, nb); });
+        run("xcd contiguous   BS512 read1+write1 nt", b2, [&](int k){ hipLaunchKernelGGL((k_one_x<2, 512, 1, 1>), dim3(nb), dim3(512), 0, 0, A[k], B[k], C[k], sink, nb); });
+        run("xcd round-robin  BS512 read2 nt", b2, [&](int k){ hipLaunchKernelGGL((k_one_x<1, 512, 1, 0>), dim3(nb), dim3(512), 0, 0, A[k], B[k], C[k], sink, nb); });
+        run("xcd contiguous   BS512 read2 nt", b2, [&](int k){ hipLaunchKernelGGL((k_one_x<1, 512, 1, 1>), dim3(nb), dim3(512), 0, 0, A[k], B[k], C[k], sink, nb); });
     }
     {
         const int nb = (int)(N / 1024); char nm[96];
