@@ -142,6 +142,33 @@ __global__ __launch_bounds__(BS) void k_one_x(const float* A, const float* B, fl
     else if (a.x + a.y + a.z + a.w == 123.456f) sink[0] = a.x;
 }
 
+// Cache-policy probe (gfx950 global_load/global_store modifiers sc0 / sc1 / nt), one float4 per thread per stream.
+#define LQ_POL_KERNEL(NAME, LDPOL, STPOL)                                                                              \
+    __global__ __launch_bounds__(512) void NAME(const float* A, const float* B, float* C, float* sink, int mode) {    \
+        const int64_t j = (int64_t)blockIdx.x * 512 + threadIdx.x;                                                     \
+        const float4* pa = (const float4*)A + j;                                                                       \
+        const float4* pb = (const float4*)B + j;                                                                       \
+        float4* pc = (float4*)C + j;                                                                                   \
+        v4f a, b;                                                                                                      \
+        if (mode == 1) {                                                                                               \
+            asm volatile("global_load_dwordx4 %0, %2, off " LDPOL "\n\tglobal_load_dwordx4 %1, %3, off " LDPOL          \
+                         "\n\ts_waitcnt vmcnt(0)" : "=&v"(a), "=&v"(b) : "v"(pa), "v"(pb) : "memory");                 \
+            if (a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w == 123.456f) sink[0] = a.x;                              \
+        } else {                                                                                                       \
+            asm volatile("global_load_dwordx4 %0, %1, off " LDPOL "\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(pa) : "memory"); \
+            a.x += 1.0f;                                                                                               \
+            asm volatile("global_store_dwordx4 %0, %1, off " STPOL : : "v"(pc), "v"(a) : "memory");                    \
+        }                                                                                                              \
+    }
+LQ_POL_KERNEL(k_pol_plain, "", "")
+LQ_POL_KERNEL(k_pol_nt, "nt", "nt")
+LQ_POL_KERNEL(k_pol_sc1nt, "sc1 nt", "sc1 nt")
+LQ_POL_KERNEL(k_pol_sc0sc1nt, "sc0 sc1 nt", "sc0 sc1 nt")
+LQ_POL_KERNEL(k_pol_sc1, "sc1", "sc1")
+LQ_POL_KERNEL(k_pol_sc0sc1, "sc0 sc1", "sc0 sc1")
+LQ_POL_KERNEL(k_pol_ldnt_stsc, "nt", "sc0 sc1 nt")
+LQ_POL_KERNEL(k_pol_ldsc_stnt, "sc0 sc1 nt", "nt")
+
 int main(int argc, char** argv) {
     const int64_t N = 256ll * 3 * 224 * 224;
     const int SETS = 4;
@@ -176,6 +203,13 @@ int main(int argc, char** argv) {
     TB("read2", 1, b2, 256) TB("read2", 1, b2, 512) TB("read2", 1, b2, 1024)
     TB("read1+write1", 2, b2, 256) TB("read1+write1", 2, b2, 512) TB("read1+write1", 2, b2, 1024)
     TB("read2+write1", 3, b3, 256) TB("read2+write1", 3, b3, 512) TB("read2+write1", 3, b3, 1024)
+    }
+#define POL(K, label) { const int nb = (int)(N / 4 / 512); \
+        run("policy " label "  read1+write1", b2, [&](int k){ hipLaunchKernelGGL(K, dim3(nb), dim3(512), 0, 0, A[k], B[k], C[k], sink, 2); }); \
+        run("policy " label "  read2", b2, [&](int k){ hipLaunchKernelGGL(K, dim3(nb), dim3(512), 0, 0, A[k], B[k], C[k], sink, 1); }); }
+    for (int rep = 0; rep < 2; ++rep) {
+        POL(k_pol_plain, "(none)      ") POL(k_pol_nt, "nt          ") POL(k_pol_sc1nt, "sc1 nt      ") POL(k_pol_sc0sc1nt, "sc0 sc1 nt  ")
+        POL(k_pol_sc1, "sc1         ") POL(k_pol_sc0sc1, "sc0 sc1     ") POL(k_pol_ldnt_stsc, "ld nt/st sc*") POL(k_pol_ldsc_stnt, "ld sc*/st nt")
     }
     for (int rep = 0; rep < 2; ++rep) {     // nb = N/4/512 = 18816 is a multiple of 8
         const int nb = (int)(N / 4 / 512);
