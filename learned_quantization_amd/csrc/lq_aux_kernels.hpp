@@ -141,14 +141,29 @@ __device__ __forceinline__ bool q_as_int(float x, float sg, int32_t& qi) {
     return true;
 }
 
+// IT = uint32_t below 2^31 elements: (i / inner) % G in 32-bit arithmetic (the 64-bit division expansion dominated the loop)
+template <typename IT>
 __global__ __launch_bounds__(kBlock) void k_q_minmax(const float* __restrict__ P, const float* __restrict__ s, int32_t* minmax,
-                                                     int64_t n, int64_t G, int64_t inner) {
+                                                     int64_t n64, int64_t G64, int64_t inner64) {
+    const IT n = (IT)n64, G = (IT)G64, inner = (IT)inner64;
     int32_t lo = INT32_MAX, hi = INT32_MIN;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        int32_t qi;
-        if (q_as_int(P[i], s[(i / inner) % G], qi)) {
-            lo = qi < lo ? qi : lo;
-            hi = qi > hi ? qi : hi;
+    // four independent (element, scale) loads in flight per thread; indices past the end are clamped and not counted
+    const IT stride = (IT)gridDim.x * kBlock;
+    for (IT i = (IT)blockIdx.x * kBlock + threadIdx.x; i < n; i += 4 * stride) {
+        float x[4], sg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const IT j = (n - i > (IT)u * stride) ? i + (IT)u * stride : i;
+            x[u] = P[j];
+            sg[u] = s[(j / inner) % G];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int32_t qi;
+            if (n - i > (IT)u * stride && q_as_int(x[u], sg[u], qi)) {
+                lo = qi < lo ? qi : lo;
+                hi = qi > hi ? qi : hi;
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -156,29 +171,57 @@ __global__ __launch_bounds__(kBlock) void k_q_minmax(const float* __restrict__ P
         lo = l2 < lo ? l2 : lo;
         hi = h2 > hi ? h2 : hi;
     }
+    // one pair of atomics per BLOCK: every wave hitting the same two words serialises at ~12 ns per atomic
+    // (16 K waves used to cost 100-400 us here)
+    __shared__ int32_t wlo[kBlock / 64], whi[kBlock / 64];
     if ((threadIdx.x & 63) == 0) {
-        if (lo != INT32_MAX) atomicMin(&minmax[0], lo);
-        if (hi != INT32_MIN) atomicMax(&minmax[1], hi);
+        wlo[threadIdx.x >> 6] = lo;
+        whi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            lo = wlo[w] < lo ? wlo[w] : lo;
+            hi = whi[w] > hi ? whi[w] : hi;
+        }
+        // the range only widens: a block whose extreme does not beat the value it can currently see has nothing to add
+        // (a stale read only costs a redundant atomic), so most blocks skip the serialised same-address update
+        volatile int32_t* cur = minmax;
+        if (lo != INT32_MAX && lo < cur[0]) atomicMin(&minmax[0], lo);
+        if (hi != INT32_MIN && hi > cur[1]) atomicMax(&minmax[1], hi);
     }
 }
 
 constexpr int kHistLds = 4096;   // bins privatised in LDS per block (the trained models use a few dozen integers)
 
+template <typename IT>
 __global__ __launch_bounds__(kBlock) void k_q_histogram(const float* __restrict__ P, const float* __restrict__ s, int32_t qmin,
-                                                        int64_t nbins, uint32_t* bins, int64_t n, int64_t G, int64_t inner) {
+                                                        int64_t nbins, uint32_t* bins, int64_t n64, int64_t G64, int64_t inner64) {
+    const IT n = (IT)n64, G = (IT)G64, inner = (IT)inner64;
     __shared__ uint32_t lh[kHistLds];
     const bool priv = nbins <= kHistLds;
     if (priv) {
         for (int b = threadIdx.x; b < (int)nbins; b += kBlock) lh[b] = 0u;
         __syncthreads();
     }
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        int32_t qi;
-        if (!q_as_int(P[i], s[(i / inner) % G], qi)) continue;
-        const int64_t b = (int64_t)qi - (int64_t)qmin;
-        if (b < 0 || b >= nbins) continue;
-        if (priv) atomicAdd(&lh[b], 1u);
-        else atomicAdd(&bins[b], 1u);
+    const IT stride = (IT)gridDim.x * kBlock;
+    for (IT i = (IT)blockIdx.x * kBlock + threadIdx.x; i < n; i += 4 * stride) {
+        float x[4], sg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const IT j = (n - i > (IT)u * stride) ? i + (IT)u * stride : i;
+            x[u] = P[j];
+            sg[u] = s[(j / inner) % G];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int32_t qi;
+            if (!(n - i > (IT)u * stride) || !q_as_int(x[u], sg[u], qi)) continue;
+            const int64_t b = (int64_t)qi - (int64_t)qmin;
+            if (b < 0 || b >= nbins) continue;
+            if (priv) atomicAdd(&lh[b], 1u);
+            else atomicAdd(&bins[b], 1u);
+        }
     }
     if (priv) {
         __syncthreads();

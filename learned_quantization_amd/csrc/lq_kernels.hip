@@ -889,8 +889,10 @@ int lq_q_minmax(const float* P, const float* s, int32_t* minmax_dev, int64_t out
     LQ_REQUIRE_PTR(minmax_dev);
     const int64_t n = outer * G * inner;
     int64_t blocks = ceil_div(n, (int64_t)kBlock * 8);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_q_minmax, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, P, s, minmax_dev, n, G, inner);
+    if (blocks > 1024) blocks = 1024;      // 4 blocks per CU; 2 x 1024 same-address atomics at the end
+    // grid-stride index + stride stays below 2^32 for n < 2^31 (stride <= 1024 * 256)
+    if (n < 2147483648ll) hipLaunchKernelGGL(k_q_minmax<uint32_t>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, P, s, minmax_dev, n, G, inner);
+    else hipLaunchKernelGGL(k_q_minmax<int64_t>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, P, s, minmax_dev, n, G, inner);
     return check_hip("q minmax launch");
 }
 
@@ -905,7 +907,8 @@ int lq_q_histogram(const float* P, const float* s, int32_t qmin, int64_t nbins, 
     const int64_t n = outer * G * inner;
     int64_t blocks = ceil_div(n, (int64_t)kBlock * 16);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_q_histogram, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, P, s, qmin, nbins, bins_dev, n, G, inner);
+    if (n < 2147483648ll) hipLaunchKernelGGL(k_q_histogram<uint32_t>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, P, s, qmin, nbins, bins_dev, n, G, inner);
+    else hipLaunchKernelGGL(k_q_histogram<int64_t>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, P, s, qmin, nbins, bins_dev, n, G, inner);
     return check_hip("q histogram launch");
 }
 
