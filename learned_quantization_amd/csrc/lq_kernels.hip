@@ -99,7 +99,12 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
                 const int64_t k = 64 / C;
                 RB = ceil_div(ceil_div(16384, C), 4 * k) * 4 * k;
             } else {
-                RB = 128;
+                // 128 rows per block for streaming sizes; small matrices get shorter row blocks (about 512 blocks in all) so
+                // that a wave walks its rows in one or two dependent load rounds instead of eight (784 x 128 Dense, column-wise:
+                // scale-gradient traversal 12.5 -> 5.9 us, forward 9.4 -> 4.3 us)
+                RB = ceil_div(outer * ceil_div(C, 256), 512);
+                RB = ceil_div(RB, 16) * 16;
+                if (RB > 128) RB = 128;
             }
             if (RB > outer) RB = outer;
             if (!nby) nby = ceil_div(outer, RB);

@@ -35,11 +35,14 @@ def timed(fn, steps, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--only", default=None, help="config:orientation, e.g. mnist:columnwise")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
     for config, lam in (("mnist", 1e-10), ("cifar", 1e-11), ("imagenette", 1e-11)):
         for orient in (("rowwise", "columnwise", "scalar") if config == "mnist" else ("rowwise", "columnwise", "channelwise", "scalar")):
+            if args.only and args.only != f"{config}:{orient}":
+                continue
             lq.reset_layer_names()
             model = lq.build_model(config, mode="nq", value=lam, seed=42, orientation=orient, device=dev)
             batch = lq.FakeQuantBatch(model)
