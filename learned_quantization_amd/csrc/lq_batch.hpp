@@ -86,8 +86,8 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
     }
 }
 
-template <int OP>
-__global__ __launch_bounds__(64) void k_batch_finalize(const Task* __restrict__ tasks, int ntasks, uint32_t* ws) {
+template <int OP, int BS = 64>     // BS = 256 when some group of the batch has more than 256 partials (host decides)
+__global__ __launch_bounds__(BS) void k_batch_finalize(const Task* __restrict__ tasks, int ntasks, uint32_t* ws) {
     const int ti = find_task(tasks, ntasks, blockIdx.x, true);
     const Task& t = tasks[ti];
     Params p = t.p;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void k_batch_finalize(const Task* __restrict__ 
     f.o0 = (OP == OP_MAXBIN_FWD) ? t.mb : t.ds;
     f.o1 = nullptr;
     f.o2 = (OP == OP_MAXBIN_FWD) ? t.ties : nullptr;
-    finalize_block_body<OP, 64>(p, f, (int64_t)(blockIdx.x - t.first_group));
+    finalize_block_body<OP, BS>(p, f, (int64_t)(blockIdx.x - t.first_group));
 }
 
 // Scale gradients of the MaxBin (kind 0) and Inverse (kind 2) penalty terms for every group of every tensor:

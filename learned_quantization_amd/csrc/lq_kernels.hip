@@ -795,6 +795,14 @@ int lq_batch_forward(const lq_batch* b, void* stream) {
     return check_hip("batch forward launch");
 }
 
+}  // extern "C"
+static bool batch_wide_finalize(const std::vector<lq::Task>& h) {
+    for (const lq::Task& t : h)
+        if (t.n1 * t.n2 > 256) return true;
+    return false;
+}
+extern "C" {
+
 int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream) {
     if (!b) return fail(LQ_EINVAL, "lq_batch_scale_grad: NULL batch");
     if (b->bwd_h.empty()) return LQ_OK;
@@ -819,8 +827,12 @@ int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, siz
                        (int)b->bwd_h.size(), (uint32_t*)ws, pk, 1, cf);
     int rc = check_hip("batch scale-grad launch");
     if (rc) return rc;
-    hipLaunchKernelGGL((k_batch_finalize<OP_BWD>), dim3(b->bwd_groups), dim3(64), 0, (hipStream_t)stream, b->bwd_d,
-                       (int)b->bwd_h.size(), (uint32_t*)ws);
+    if (batch_wide_finalize(b->bwd_h))
+        hipLaunchKernelGGL((k_batch_finalize<OP_BWD, 256>), dim3(b->bwd_groups), dim3(256), 0, (hipStream_t)stream, b->bwd_d,
+                           (int)b->bwd_h.size(), (uint32_t*)ws);
+    else
+        hipLaunchKernelGGL((k_batch_finalize<OP_BWD>), dim3(b->bwd_groups), dim3(64), 0, (hipStream_t)stream, b->bwd_d,
+                           (int)b->bwd_h.size(), (uint32_t*)ws);
     return check_hip("batch finalize launch");
 }
 
