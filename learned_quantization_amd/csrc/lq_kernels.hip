@@ -96,8 +96,12 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
                 const int64_t k = 64 / C;
                 RB = ceil_div(ceil_div(outer, nby), 4 * k) * 4 * k;
             } else if (C <= 64) {
+                // ~16 K elements per block, but at least ~1024 blocks' worth of parallelism for small matrices: a block whose
+                // waves walk 1656 rows of 10 columns needs 17 dependent load rounds (12 us for 64 K elements)
                 const int64_t k = 64 / C;
                 RB = ceil_div(ceil_div(16384, C), 4 * k) * 4 * k;
+                const int64_t rb_par = ceil_div(ceil_div(outer, 1024), 4 * k) * 4 * k;
+                if (rb_par < RB) RB = rb_par;
             } else {
                 // 128 rows per block for streaming sizes; small matrices get shorter row blocks (about 512 blocks in all) so
                 // that a wave walks its rows in one or two dependent load rounds instead of eight (784 x 128 Dense, column-wise:
@@ -304,7 +308,9 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
 template <int OP>
 static int launch_finalize(const Params& p, FinGeom f, hipStream_t st) {
     const int64_t n = f.n1 * f.n2;
-    if (n <= 32) {
+    // one thread per group walks its partials one after the other: right for very many groups (throughput) or a handful of
+    // partials, a latency trap otherwise (32 partials: ~10 us) -- few groups get one wave each instead
+    if (n <= 4 || (n <= 32 && f.groups >= 2048)) {
         hipLaunchKernelGGL((k_finalize_thread<OP>), dim3((unsigned)ceil_div(f.groups, kBlock)), dim3(kBlock), 0, st, p, f);
     } else if (n <= 256) {
         hipLaunchKernelGGL((k_finalize_block<OP, 64>), dim3((unsigned)f.groups), dim3(64), 0, st, p, f);
