@@ -157,10 +157,17 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
             pl.lpr_log2 = lg;
         }
         pl.np = R * pl.nc;
-        pl.gstride = pl.nc;
-        pl.n1 = f_outer;
-        pl.stride1 = G * pl.nc;
-        pl.n2 = pl.nc;
+        if (pl.mode == MODE_ROW_SMALL) {   // one partial per row, stored group-major: g * outer + o
+            pl.gstride = f_outer;
+            pl.n1 = f_outer;
+            pl.stride1 = 1;
+            pl.n2 = 1;
+        } else {
+            pl.gstride = pl.nc;
+            pl.n1 = f_outer;
+            pl.stride1 = G * pl.nc;
+            pl.n2 = pl.nc;
+        }
     }
     return pl;
 }

@@ -27,7 +27,20 @@ LAYOUTS = [("flat scalar (1,1,n)", lambda n: (1, 1, n)),
            ("channelwise (9,n/9/512,512)", lambda n: (9, max(1, n // 9 // 512), 512)),
            ("column C=128 (n/128,128,1)", lambda n: (n // 128, 128, 1)),
            ("column C=10 (n/10,10,1)", lambda n: (n // 10, 10, 1)),
-           ("column C=512 inner=1 (n/512,512,1)", lambda n: (n // 512, 512, 1))]
+           ("column C=512 inner=1 (n/512,512,1)", lambda n: (n // 512, 512, 1)),
+           ("rows of 32 (1,n/32,32)", lambda n: (1, n // 32, 32)),
+           ("rows of 100 (1,n/100,100)", lambda n: (1, n // 100, 100)),
+           ("rows of 1000 (1,n/1000,1000)", lambda n: (1, n // 1000, 1000)),
+           ("rows of 1031 (1,n/1031,1031)", lambda n: (1, n // 1031, 1031)),
+           ("rows of 20000 (1,n/20000,20000)", lambda n: (1, max(1, n // 20000), 20000)),
+           ("G=16 inner=64 (n/1024,16,64)", lambda n: (n // 1024, 16, 64)),
+           ("G=256 inner=8 (n/2048,256,8)", lambda n: (n // 2048, 256, 8)),
+           ("G=3 inner=big (1,3,n/3)", lambda n: (1, 3, n // 3)),
+           ("outer=64 G=3 (64,3,n/192)", lambda n: (64, 3, n // 192))]
+if len(sys.argv) > 1 and sys.argv[1] == "more":
+    LAYOUTS = LAYOUTS[7:]
+else:
+    LAYOUTS = LAYOUTS[:7]
 for name, mk in LAYOUTS:
     row = []
     for n in (65536, 262144, 1048576, 4194304, 16777216):
