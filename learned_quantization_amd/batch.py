@@ -85,6 +85,13 @@ class FakeQuantBatch:
         self.ws = torch.empty(lib.lq_batch_workspace_bytes(handle), dtype=torch.uint8, device=self.device)
         self.hyper = dict(lr=lr, betas=betas, eps=eps, mode=mode)
         self._data_ptrs = [(e.param.data_ptr(), e.nested.scale.data_ptr()) for e in self.entries]
+        # per-step host work is kept to list lookups: the flat (param, scale, ...) argument list of the autograd node and,
+        # per layer, which outputs are its kernel and its bias
+        self._flat = [t for e in self.entries for t in (e.param, e.nested.scale)]
+        slots = {}
+        for i, e in enumerate(self.entries):
+            slots.setdefault(id(e.layer), [e.layer, None, None])[1 + e.slot] = i
+        self._layer_slots = list(slots.values())
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -105,16 +112,10 @@ class FakeQuantBatch:
     def quantize_all(self):
         """One launch: fake-quantise every kernel/bias; layers pick the results up in their next call."""
         self._check_pointers()
-        flat = []
-        for e in self.entries:
-            flat.append(e.param)
-            flat.append(e.nested.scale)
-        outs = _BatchFn.apply(self, *flat)
-        per_layer = {}
-        for e, o in zip(self.entries, outs):
-            per_layer.setdefault(id(e.layer), [e.layer, None, None])[1 + e.slot] = o
-        for layer, qk, qb in per_layer.values():
-            layer._q_pre = (qk, qb)
+        outs = _BatchFn.apply(self, *self._flat)
+        for layer, ik, ib in self._layer_slots:
+            # plain instance attribute (not a Parameter/Module): written through __dict__, nn.Module.__setattr__ costs ~3 us
+            layer.__dict__["_q_pre"] = (None if ik is None else outs[ik], None if ib is None else outs[ib])
         return outs
 
     # ------------------------------------------------------------------ custom loss terms
