@@ -148,6 +148,12 @@ def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
         )
     if t.dtype != torch.float32:
         raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        # the launches go to the current device's stream: a tensor of another GPU would be dereferenced from the wrong device
+        raise RuntimeError(
+            f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: this library runs one "
+            "process per GPU -- call torch.cuda.set_device(...) (or use `with torch.cuda.device(...)`) before using its ops"
+        )
     return t if t.is_contiguous() else t.contiguous()
 
 
