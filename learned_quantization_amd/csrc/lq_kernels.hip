@@ -67,6 +67,15 @@ struct Plan {
 
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Chunks of CH elements per row of length L.  A tail of at most CH/8 elements is folded into the previous chunk (the
+// traversal's last chunk takes whatever remains) instead of getting a block of its own.
+static int64_t row_chunks(int64_t L, int64_t CH) {
+    int64_t nc = ceil_div(L, CH);
+    const int64_t r = L % CH;
+    if (nc > 1 && r != 0 && r * 8 <= CH) nc -= 1;
+    return nc;
+}
+
 static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0) {
     Plan pl;
     memset(&pl, 0, sizeof(pl));
@@ -143,7 +152,7 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
                 if ((v == 256 || v == 512 || v == 1024) && L >= v * 4) pl.bs = v;
             }
             pl.CH = pl.bs * 4;
-            pl.nc = ceil_div(L, pl.CH);
+            pl.nc = row_chunks(L, pl.CH);
         } else {
             pl.mode = MODE_ROW_SMALL;
             pl.CH = (int)L;
@@ -263,7 +272,7 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         const bool want_u2 = tune_u2 >= 0 ? tune_u2 == 1 : (OP == OP_BWD || p.tmode >= 1);
         const bool u2 = (OP == OP_BWD || OP == OP_FUSED) && want_u2 && vec && nt && pl.bs == 512;
         if (u2) {
-            const int64_t nc2 = ceil_div(pl.L, (int64_t)pl.bs * 8);
+            const int64_t nc2 = row_chunks(pl.L, (int64_t)pl.bs * 8);
             const dim3 grid2 = grid3d ? dim3((unsigned)nc2, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)(pl.R * nc2));
             hipLaunchKernelGGL((k_row_stream<OP, 4, 512, 1, 2>), grid2, dim3(512), 0, st, p, pl.L, nc2, grid3d);
             // the finalize that follows must walk the partial layout this launch produced

@@ -41,7 +41,9 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
     constexpr int CH = BS * 4 * U;
     const int64_t base = row * L + ck * (int64_t)CH;
     const int64_t rem = L - ck * (int64_t)CH;
-    const int len = rem < (int64_t)CH ? (int)rem : CH;
+    // The last chunk of a row takes everything that remains: at most CH, or up to CH + CH/8 when the host folded a short
+    // tail into it (row_chunks(): a row of 4100 elements is 2 chunks of 2048 + 2052, not 3 with an almost empty block).
+    const int len = (ck == nc - 1) ? (int)rem : CH;
     Acc acc = O::template init<Acc>();
 
     if (VEC == 4) {
@@ -90,6 +92,25 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
                 if (O::kStore) store4<NT>(p.out + i[u], r);
             }
         }
+        if (__builtin_expect(len4 > BS * U, 0)) {      // folded tail: fewer than BS*U/8 further float4, one more pass
+            const int j = BS * U + (int)threadIdx.x;
+            if (j < len4) {
+                const int64_t ie = vbase + (int64_t)j * 4;
+                const float4 xe = load4<NT>(p.P + ie);
+                float4 de = xe;
+                if (O::kDy) de = load4<NT>(p.dy + ie);
+                float4 r;
+                if constexpr (O::kVec4) {
+                    r = O::elem4(p, ctx, ie, xe, de, acc);
+                } else {
+                    r.x = O::elem(p, ctx, ie + 0, xe.x, O::kDy ? de.x : 0.f, acc);
+                    r.y = O::elem(p, ctx, ie + 1, xe.y, O::kDy ? de.y : 0.f, acc);
+                    r.z = O::elem(p, ctx, ie + 2, xe.z, O::kDy ? de.z : 0.f, acc);
+                    r.w = O::elem(p, ctx, ie + 3, xe.w, O::kDy ? de.w : 0.f, acc);
+                }
+                if (O::kStore) store4<NT>(p.out + ie, r);
+            }
+        }
         // scalar head (threads 0..head-1) and tail (threads 8..8+tail-1): at most 6 elements per chunk
         const int tail = vlen & 3;
         const int t = (int)threadIdx.x;
@@ -115,6 +136,10 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
                 float r = O::elem(p, ctx, base + j, x[u], d[u], acc);
                 if (O::kStore) p.out[base + j] = r;
             }
+        }
+        for (int j = 4 * U * BS + (int)threadIdx.x; j < len; j += BS) {      // folded tail
+            float r = O::elem(p, ctx, base + j, p.P[base + j], O::kDy ? p.dy[base + j] : 0.f, acc);
+            if (O::kStore) p.out[base + j] = r;
         }
     }
     if (O::kReduce) {
