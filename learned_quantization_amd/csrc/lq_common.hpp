@@ -37,6 +37,12 @@ struct Params {
     uint32_t* pb;
     float* pc;
     int64_t outer, G, inner;
+    // direct emit (scale-gradient ops whose groups have exactly one partial: biases, row-wise Dense, one row per group):
+    // the traversal writes the op's outputs itself and the finalize launch is skipped
+    int direct;
+    float* e0;           // ds[G]
+    float* e1;           // optional parts[3*G]
+    double ecount;       // elements per group
 };
 
 // Per-group context, loaded once per row / column.

@@ -440,7 +440,15 @@ int lq_fq_scale_grad(const float* P, const float* s, const float* dy, float lamb
     p.lam = lambda;
     p.tmode = (lambda < 4.0e-4f) ? 0 : ((lambda <= 0.25f) ? 1 : 2);   // NaN lambda -> 2
     if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
+    const bool direct = pl.n1 * pl.n2 == 1;      // one partial per group: the traversal emits ds itself, no finalize launch
+    if (direct) {
+        p.direct = 1;
+        p.e0 = ds;
+        p.e1 = parts;
+        p.ecount = (double)outer * (double)inner;
+    }
     if ((rc = launch_traverse<OP_BWD>(pl, p, (hipStream_t)stream))) return rc;
+    if (direct) return LQ_OK;
     FinGeom f = group_geom(pl, outer, G, inner);
     f.o0 = ds;
     f.o1 = parts;
@@ -463,7 +471,15 @@ int lq_fq_fwd_bwd_fused(const float* P, const float* s, const float* dy, float l
     p.tmode = (lambda < 4.0e-4f) ? 0 : ((lambda <= 0.25f) ? 1 : 2);   // NaN lambda -> 2
     p.out = out;
     if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
+    const bool direct = pl.n1 * pl.n2 == 1;
+    if (direct) {
+        p.direct = 1;
+        p.e0 = ds;
+        p.e1 = nullptr;
+        p.ecount = (double)outer * (double)inner;
+    }
     if ((rc = launch_traverse<OP_FUSED>(pl, p, (hipStream_t)stream))) return rc;
+    if (direct) return LQ_OK;
     FinGeom f = group_geom(pl, outer, G, inner);
     f.o0 = ds;
     return launch_finalize<OP_FUSED>(p, f, (hipStream_t)stream);

@@ -41,6 +41,22 @@ __device__ __forceinline__ void write_partial(const Params& p, int64_t idx, cons
     p.pc[idx] = acc.c;
 }
 
+template <int OP>
+__device__ __forceinline__ void emit_direct(const Params& p, int64_t g, const Acc& acc);     // lq_traverse.hpp (needs FinT)
+
+// What every traversal calls: the partial triple of work unit `idx`, or -- when the host saw that each group has exactly one
+// partial (then idx is the group index) -- the finished outputs.
+template <int OP>
+__device__ __forceinline__ void write_partial_t(const Params& p, int64_t idx, const Acc& acc) {
+    if constexpr (OP == OP_BWD || OP == OP_FUSED) {
+        if (p.direct) {
+            emit_direct<OP>(p, idx, acc);
+            return;
+        }
+    }
+    write_partial(p, idx, acc);
+}
+
 // ------------------------------------------------------------------------------------------
 //  DPP wave reduction for the standard accumulator (a: max, b: add, c: add) -- VALU only, no LDS
 //  crossbar traffic: quad_perm x2, row_half_mirror, row_mirror give every lane of a 16-lane row

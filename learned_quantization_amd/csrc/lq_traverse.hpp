@@ -148,7 +148,7 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
         } else {
             block_reduce<O, Acc, BS>(acc);
         }
-        if (threadIdx.x == 0) write_partial(p, row * nc + ck, acc);
+        if (threadIdx.x == 0) write_partial_t<OP>(p, row * nc + ck, acc);
     }
 }
 
@@ -219,7 +219,7 @@ __device__ __forceinline__ void row_small_body(const Params& p, int64_t R, int L
             // group-major partials (index g*outer + o for row o*G + g): the finalize of group g then reads one contiguous
             // run instead of every G-th word (16 groups x 16384 rows: 29.5 us of strided gathers)
             const int64_t o = row / p.G, g = row - o * p.G;
-            write_partial(p, (p.G > 1 ? g * p.outer + o : row), acc);
+            write_partial_t<OP>(p, (p.G > 1 ? g * p.outer + o : row), acc);
         }
     }
 }
@@ -314,7 +314,7 @@ __device__ __forceinline__ void col_tile_body(const Params& p, int64_t C, int64_
                 Acc r = lds[lane * VW + k];
 #pragma unroll
                 for (int ww = 1; ww < 4; ++ww) O::merge(r, lds[ww * (64 * VW) + lane * VW + k]);   // fixed wave order
-                write_partial(p, by * C + col0 + k, r);
+                write_partial_t<OP>(p, by * C + col0 + k, r);
             }
         }
     }
@@ -360,7 +360,7 @@ __device__ __forceinline__ void col_small_body(const Params& p, int C, int64_t R
             Acc r = O::template init<Acc>();
             for (int ww = 0; ww < 4; ++ww)
                 for (int q = 0; q < k; ++q) O::merge(r, lds[ww * 64 + q * C + (int)threadIdx.x]);      // fixed order
-            write_partial(p, by * C + threadIdx.x, r);
+            write_partial_t<OP>(p, by * C + threadIdx.x, r);
         }
     }
 }
@@ -442,7 +442,7 @@ __device__ __forceinline__ void col_periodic4_body(const Params& p, int C, int64
         if ((int)threadIdx.x < C) {
             Acc r = lds2[threadIdx.x];
             for (int hh = 1; hh < H; ++hh) O::merge(r, lds2[hh * C + (int)threadIdx.x]);                  // fixed order
-            write_partial(p, blk * C + threadIdx.x, r);
+            write_partial_t<OP>(p, blk * C + threadIdx.x, r);
         }
     }
 }
@@ -532,6 +532,22 @@ struct FinT<OP_DIFF_BWD> {
         f.o0[g] = (float)a.c;
     }
 };
+
+template <int OP>
+__device__ __forceinline__ void emit_direct(const Params& p, int64_t g, const Acc& acc) {
+    FinGeom f;
+    f.groups = p.G;
+    f.gstride = f.n1 = f.stride1 = f.n2 = 0;
+    f.count = p.ecount;
+    f.o0 = p.e0;
+    f.o1 = p.e1;
+    f.o2 = nullptr;
+    AccW w;
+    w.a = acc.a;
+    w.b = (double)acc.b;
+    w.c = (double)acc.c;
+    FinT<OP>::emit(p, f, g, w);        // same arithmetic as the finalize of a single partial: bit-identical outputs
+}
 
 template <class O>
 __device__ __forceinline__ AccW load_partial(const Params& p, int64_t idx) {
