@@ -100,3 +100,86 @@ def penalty(kind, layers):
         num += nK * tK + nb * tb
         den += nK + nb
     return num / den
+
+
+# --------------------------------------------------------------------------- #
+#  Float64 gradients of the penalty terms, with the condition-number yardstick.
+#  A float32 implementation that sums n signed terms t_i cannot be held to a bound relative to |sum t_i| (the
+#  terms cancel); the right yardstick is sum |t_i|.  Every function returns, next to the float64 gradient, the
+#  float64 sum of the absolute values of the terms that gradient is a sum of (for single-term quantities that is
+#  |gradient| itself).  tests/_bounds.py asserts |got - f64| <= 1e-5 * sum|t_i|.
+#  Formulas: chapter3.tex:242-282 (MaxBin), :289-311 (Inverse), :317-337 (Difference); d|x| = sign(x);
+#  reduce_max routes its gradient evenly to the tied maxima (TensorFlow math_grad._MinOrMaxGrad).
+# --------------------------------------------------------------------------- #
+def maxbin_term_grads(P, s, c, outer, G, inner):
+    """d(c * mean_g max_i |P_i|/s_g): returns (dP, ds, ds_abs)."""
+    P = np.asarray(P, np.float64).reshape(-1)
+    s = np.asarray(s, np.float64).reshape(-1)
+    gid = group_ids(outer, G, inner)
+    t = np.abs(P) / s[gid]
+    m = np.full(G, -np.inf)
+    np.maximum.at(m, gid, t)
+    ind = t == m[gid]
+    cnt = np.bincount(gid, weights=ind.astype(np.float64), minlength=G)
+    g = ind / cnt[gid] * (float(c) / G)                         # gradient with respect to t
+    dP = g / s[gid] * np.sign(P)
+    terms = -g * t / s[gid]
+    ds = np.bincount(gid, weights=terms, minlength=G)
+    ds_abs = np.bincount(gid, weights=np.abs(terms), minlength=G)
+    return dP, ds, ds_abs
+
+
+def difference_term_grads(P, s, c, outer, G, inner):
+    """d(c * mean |P - P/s|): returns (dP, ds, ds_abs)."""
+    P = np.asarray(P, np.float64).reshape(-1)
+    s = np.asarray(s, np.float64).reshape(-1)
+    gid = group_ids(outer, G, inner)
+    pq = P / s[gid]
+    g = np.sign(P - pq) * (float(c) / P.size)
+    dP = g - g / s[gid]
+    terms = g * pq / s[gid]
+    ds = np.bincount(gid, weights=terms, minlength=G)
+    ds_abs = np.bincount(gid, weights=np.abs(terms), minlength=G)
+    return dP, ds, ds_abs
+
+
+def inverse_term_grads(s, c):
+    """d(c * mean 1/where(s == 0, eps, s)): returns (ds, ds_abs); no gradient reaches an exactly zero scale."""
+    s = np.asarray(s, np.float64).reshape(-1)
+    s_nz = np.where(s == 0.0, EPS_F32, s)
+    ds = np.where(s == 0.0, 0.0, -(float(c) / s.size) / (s_nz * s_nz))
+    return ds, np.abs(ds)
+
+
+def term_abs(kind, P, s, outer, G, inner):
+    """sum of |terms| of the float64 VALUE of one tensor term (every term is non-negative: it equals the value)."""
+    if kind == "maxbin":
+        return abs(maxbin_term(P, s, outer, G, inner))
+    if kind == "difference":
+        return abs(difference_term(P, s, outer, G, inner))
+    return abs(inverse_term(s))
+
+
+def penalty_grads(kind, layers, rate):
+    """Gradients of ``rate * penalty(kind, layers)`` for every tensor: list of dicts (one per layer) with the float64
+    arrays dK, dsK, dsK_abs, db, dsb, dsb_abs (dK/db are None for the inverse penalty, which reads only scales).
+    The coefficient of tensor i's term is rate * numel_i / sum(numel)  (custom_loss_functions.py:110-116)."""
+    den = sum(float(np.size(K)) + float(np.size(b)) for K, sK, dK, b, sb, db in layers)
+    out = []
+    for K, sK, dK, b, sb, db in layers:
+        cK, cb = rate * float(np.size(K)) / den, rate * float(np.size(b)) / den
+        e = {}
+        if kind == "maxbin":
+            e["dK"], e["dsK"], e["dsK_abs"] = maxbin_term_grads(K, sK, cK, *dK)
+            e["db"], e["dsb"], e["dsb_abs"] = maxbin_term_grads(b, sb, cb, *db)
+        elif kind == "difference":
+            e["dK"], e["dsK"], e["dsK_abs"] = difference_term_grads(K, sK, cK, *dK)
+            e["db"], e["dsb"], e["dsb_abs"] = difference_term_grads(b, sb, cb, *db)
+        elif kind == "inverse":
+            e["dK"] = e["db"] = None
+            e["dsK"], e["dsK_abs"] = inverse_term_grads(sK, cK)
+            e["dsb"], e["dsb_abs"] = inverse_term_grads(sb, cb)
+        else:
+            raise ValueError(kind)
+        out.append(e)
+    return out

@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage: tools/prof_shapes.sh <outdir> [case ...]      (run on the GPU box, from the repo root)
+# rocprofv3 evidence for the non-BENCH traversal modes: per case one `--kernel-trace --stats` pass and three `--pmc`
+# passes (FETCH_SIZE / WRITE_SIZE separately: TCC slot limits; one SQ pass with the wait split and the LDS counters).
+# The profiled program (tools/shape_case.py) stands directly behind `--`.  tools/prof_shapes_summary.py folds the CSVs.
+out=$1; shift
+cases=("$@")
+if [ ${#cases[@]} -eq 0 ]; then
+  cases=("nhwc_c256:150528,256,1" "nhwc_c64:602112,64,1" "nhwc_c3:12845056,3,1" "col_6144:6144,6144,1" "inner8:2048,2048,8"
+         "rows_1m_x32:1,1048576,32" "rows_64k_x512:1,65536,512" "bench_nchw:256,3,50176")
+fi
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+for c in "${cases[@]}"; do
+  name=${c%%:*}; d=${c##*:}; IFS=, read o g i <<< "$d"
+  mkdir -p $out/$name
+  timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/stats -- python3 tools/shape_case.py $o $g $i --iters 20 > $out/$name/stats.log 2>&1 || exit 1
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/$name/fetch -- python3 tools/shape_case.py $o $g $i --iters 6 > $out/$name/fetch.log 2>&1 || exit 1
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/$name/write -- python3 tools/shape_case.py $o $g $i --iters 6 > $out/$name/write.log 2>&1 || exit 1
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $out/$name/sq -- python3 tools/shape_case.py $o $g $i --iters 6 > $out/$name/sq.log 2>&1 || exit 1
+  echo "profiled $name"
+done
+python3 tools/prof_shapes_summary.py $out "${cases[@]}" > $out/summary.json && echo "summary written"
