@@ -19,10 +19,12 @@ processes its own 256-image shard (weak scaling) and the learned-scale gradient 
 each step -- the only exchange this path has.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  "roofline":     dominant kernel vs the 8 TB/s HBM peak, duration from HIP events recorded inside the timed
-                  region on the launch stream (every 10th step: an event pair costs ~3 us of stream time, and
-                  recording around every launch would slow the loop it measures by ~9 %); "traffic" = HBM bytes
-                  per launch from the committed rocprofv3 PMC passes (profiles/traffic.json)
+  "roofline":     K1, K2 and K4 each timed live with HIP events on the launch stream in a dedicated region right after
+                  the timed loop: a FIXED number of isolated launches per kernel (independent of --steps), the
+                  cost of an empty event pair subtracted; the traversal kernel of the two-launch calls is
+                  bracketed alone through lq_profile_mark.  "kernel" names the one with the largest total per
+                  step.  "traffic" = HBM bytes per launch from the committed rocprofv3 PMC passes
+                  (profiles/traffic.json), reported only while the kernel sources still hash to what was profiled
   "cpu_baseline": the op-for-op torch-CPU restatement of the reference path (oracle/lq_oracle_torch.py)
                   timed on this box's host cores on a bounded sample -- a baseline, not a target.
 """
@@ -60,7 +62,7 @@ def parse():
     ap.add_argument("--scale", choices=["per_channel", "per_tensor"], default="per_channel")
     ap.add_argument("--sets", type=int, default=4, help="rotating buffer sets (>= 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--event-every", type=int, default=10, help="record per-kernel HIP events every Nth timed step (0 = never)")
+    ap.add_argument("--event-every", type=int, default=0, help="(ignored: the roofline leg now runs after the timed loop)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (one graph per buffer set)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the informational extra measurements (N=1 only)")
@@ -93,6 +95,7 @@ def cpu_baseline(lam: float, budget_s: float):
     return {
         "value": n_img * reps / dt,
         "unit": "images/s",
+        "label": f"images/s on {torch.get_num_threads()} torch CPU threads (os.cpu_count() = {os.cpu_count()})",
         "cores": torch.get_num_threads(),
         "kind": "port",
         "sample": f"{reps} x (fwd+bwd of {n_img}x3x224x224 fp32, lambda={lam:g}) = {dt:.1f} s; "
@@ -100,8 +103,21 @@ def cpu_baseline(lam: float, budget_s: float):
     }
 
 
+def csrc_sha() -> str:
+    """sha256 over the kernel sources: ties profiles/traffic.json to the code it was collected on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "learned_quantization_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "lq_hip.h")]):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     args = parse()
+    # read by the HSA runtime when it initialises (the first torch.cuda call below); the host driver only supports dmabuf IPC
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,7 +136,6 @@ def main():
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
@@ -252,45 +267,75 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    ee = args.event_every
-    events = [([torch.cuda.Event(enable_timing=True) for _ in range(3)] if (ee and i % ee == 0) else None)
-              for i in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, events[i])
+        step(i)
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    events = [e for e in events if e is not None]
-    nev = max(len(events), 1)
 
-    # per-kernel durations from the HIP events recorded inside the timed region
-    if not events:
-        t_fwd = t_bwd = kt = float("nan")
-        kname, kbytes, step_bytes, extra = "n/a", 0, (BYTES_FUSED if args.variant == "fused" else BYTES_FWD + BYTES_BWD), {}
-    elif args.variant == "split" and not args.graph:
-        t_fwd = sum(e[0].elapsed_time(e[1]) for e in events) / nev * 1e-3
-        t_bwd = sum(e[1].elapsed_time(e[2]) for e in events) / nev * 1e-3
-        # Dominant kernel by rocprofv3 (profiles/r01/rocprofv3_kernel_stats_prof_split.csv): K1 k_row_stream<OP_FWD>
-        # (48.8 us) >= K2 k_row_stream<OP_BWD> (48.5 us) > K3 k_finalize_block (4.9 us).  K1 is one launch per ABI
-        # call, so the event pair brackets exactly that kernel; the K2+K3 call time is reported beside it.
-        kname, kbytes, kt = "k_row_stream<OP_FWD, 4, 512, nt>", BYTES_FWD, t_fwd
+    # ---- roofline leg: every kernel of the path, ROOF_SAMPLES isolated launches each, HIP events on the launch stream.
+    # Independent of --steps.  elapsed(ev0, ev1) around one launch = kernel duration + what an event pair costs by itself
+    # (measured on empty pairs and subtracted).  The two-launch calls record a third event between traversal and
+    # finalize (lq_profile_mark), so K2 / K4 / K3 are each bracketed alone.
+    ROOF_SAMPLES = 24
+    Ev = lambda: torch.cuda.Event(enable_timing=True)          # noqa: E731
+    mark = Ev()
+    mark.record(stream)                                        # torch creates the hipEvent_t lazily, at the first record
+    torch.cuda.synchronize(dev)
+
+    def pairs(launch, with_mark):
+        out = []
+        for j in range(ROOF_SAMPLES + 4):
+            e0, e1, em = Ev(), Ev(), (Ev() if with_mark else None)
+            if with_mark:
+                em.record(stream)
+                lib.lq_profile_mark(em.cuda_event)
+            e0.record(stream)
+            rc = launch(j % nsets)
+            e1.record(stream)
+            if with_mark:
+                lib.lq_profile_mark(None)
+            if rc:
+                _hip.check(rc, "roofline leg")
+            out.append((e0, em, e1))
+        torch.cuda.synchronize(dev)
+        return out[4:]                                          # the first four warm the path
+
+    def mean_us(vals):
+        return sum(vals) / len(vals) * 1e3
+
+    empty = mean_us([a.elapsed_time(c) for a, _, c in pairs(lambda k: 0, False)])
+    pk1 = pairs(lambda k: fwd(px[k], ps, pout[k], None, 0, outer, G, inner, sp), False)
+    pk2 = pairs(lambda k: bwd(px[k], ps, pdy[k], lam, pds, None, pws, ws_bytes, outer, G, inner, sp), True)
+    pk4 = pairs(lambda k: fused(px[k], ps, pdy[k], lam, pout[k], pds, pws, ws_bytes, outer, G, inner, sp), True)
+    t_k1 = mean_us([a.elapsed_time(c) for a, _, c in pk1]) - empty
+    t_k2 = mean_us([a.elapsed_time(m) for a, m, _ in pk2]) - empty
+    t_k3 = mean_us([m.elapsed_time(c) for _, m, c in pk2]) - empty
+    t_k4 = mean_us([a.elapsed_time(m) for a, m, _ in pk4]) - empty
+    kernels = {}
+    for name, t_us, nbytes in (("K1 k_row_stream<OP_FWD> (lq_fq_forward)", t_k1, BYTES_FWD),
+                               ("K2 k_row_stream<OP_BWD> (lq_fq_scale_grad, traversal)", t_k2, BYTES_BWD),
+                               ("K4 k_row_stream<OP_FUSED> (lq_fq_fwd_bwd_fused, traversal)", t_k4, BYTES_FUSED)):
+        gbs = nbytes / (t_us * 1e-6) / 1e9
+        kernels[name] = {"avg_launch_us": t_us, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
+    kernels["K3 k_finalize_block (second launch of lq_fq_scale_grad)"] = {"avg_launch_us": t_k3}
+    if args.variant == "split":
+        # the step runs K1, K2, K3: the dominant kernel is the one with the largest total per step
+        kname = max(list(kernels)[:2], key=lambda k: kernels[k]["avg_launch_us"])
         step_bytes = BYTES_FWD + BYTES_BWD
-        extra = {"t_fwd_us": t_fwd * 1e6, "t_bwd_plus_finalize_us": t_bwd * 1e6,
-                 "fwd_GBs": BYTES_FWD / t_fwd / 1e9, "bwd_plus_finalize_GBs": BYTES_BWD / t_bwd / 1e9,
-                 "event_samples": len(events)}
     else:
-        kt = sum(e[0].elapsed_time(e[2]) for e in events) / nev * 1e-3
-        if args.variant == "fused":
-            kname, kbytes = "k_row_stream<OP_FUSED> (+finalize)", BYTES_FUSED
-        else:
-            kname, kbytes = "graph(k_row_stream<OP_FWD>, k_row_stream<OP_BWD>, finalize)", BYTES_FWD + BYTES_BWD
-        step_bytes = kbytes
-        extra = {"t_step_kernels_us": kt * 1e6}
+        kname = list(kernels)[2]
+        step_bytes = BYTES_FUSED
+    kt = kernels[kname]["avg_launch_us"] * 1e-6
+    kbytes = kernels[kname]["algorithmic_bytes_per_launch"]
+    extra = {"kernels": kernels, "event_samples_per_kernel": ROOF_SAMPLES, "empty_event_pair_us": empty,
+             "method": "mean over isolated launches of elapsed(event before, event after) minus the empty-pair cost; "
+                       "region placed after the timed loop, independent of --steps"}
 
     # ---- informational extras (not part of `value`): other variants of the same step, 100 steps each, no events
     extras = {}
@@ -360,15 +405,22 @@ def main():
         except Exception as e:      # never let the informational extra break the bench line
             extras["e2e_cifar_cnn_bs256_nq_channelwise_hipgraph_batched"] = {"error": repr(e)[:200]}
 
-    traffic = None
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes -- only while the kernel sources still are
+    # the ones that were profiled (tools/prof_pmc.sh stores their hash next to the numbers)
+    traffic, traffic_note = None, "profiles/traffic.json absent"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                tj = json.load(f).get(args.variant, {})
-                traffic = tj.get("fwd_kernel_hbm_bytes_per_launch" if args.variant == "split" else "hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+                tj = json.load(f)
+            if tj.get("csrc_sha") != csrc_sha():
+                traffic_note = f"profiles/traffic.json was collected on other kernel sources (csrc_sha {tj.get('csrc_sha')} != {csrc_sha()}): not reported"
+            else:
+                key = "K1" if kname.startswith("K1") else ("K2" if kname.startswith("K2") else "K4")
+                traffic = tj.get("hbm_bytes_per_launch", {}).get(key)
+                traffic_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {tj.get('collected_with', 'tools/prof_pmc.sh')}, csrc_sha {tj.get('csrc_sha')}"
+        except Exception as e:
+            traffic, traffic_note = None, f"profiles/traffic.json unreadable: {e!r}"
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -393,7 +445,7 @@ def main():
                        "buffer_sets": nsets, "algorithmic_bytes_per_step": step_bytes,
                        "step_GBs": step_bytes / (elapsed / args.steps) / 1e9},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": kbytes, "avg_launch_us": kt * 1e6, **extra,
                          # math-free kernels of the same shape on this device class (profiles/r01_membench.txt): what a
                          # streaming kernel can reach of the 8 TB/s spec peak

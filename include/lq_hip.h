@@ -195,8 +195,11 @@ int lq_batch_scale_adam(const lq_batch* batch, double lr, double beta1, double b
  * constant coeff[i] = gamma * numel_i / normalizer -- no autograd node per tensor is needed:
  *   grad[i][...] += coeff[i] * d term_i / d P_i     (MaxBin, Difference; accumulated into the existing gradient)
  *   ds_i[...]     = coeff[i] * d term_i / d s_i     (written to the descriptors' ds buffers)
- * coeff: host array [n]; grad: host array [n] of device pointers (unused for LQ_PENALTY_INVERSE).                 */
+ * coeff: host array [n]; grad: host array [n] of device pointers (unused for LQ_PENALTY_INVERSE).
+ * kind | LQ_PENALTY_ACCUMULATE_DS: ds_i[...] += ... instead of = (a nested-quantization layer trained WITH a loss term:
+ * the penalty's scale gradient is added to the hand-written one already in the buffer; no reference call site).     */
 typedef enum lq_penalty_kind { LQ_PENALTY_MAXBIN = 0, LQ_PENALTY_DIFFERENCE = 1, LQ_PENALTY_INVERSE = 2 } lq_penalty_kind;
+#define LQ_PENALTY_ACCUMULATE_DS 0x100
 int lq_batch_penalty_grads(const lq_batch* batch, int kind, const float* coeff, float* const* grad,
                            void* ws, size_t ws_bytes, void* stream);
 
@@ -234,6 +237,13 @@ int lq_selftest_ratio_division(uint64_t seed, uint32_t blocks, uint32_t pairs_pe
  * lq_math.hpp): random s in [2^-40, 2^40], random x in [2^-80, 2^81), both signs.  Expected: 0 mismatches.      */
 int lq_selftest_uniform_division(uint64_t seed, uint32_t blocks, uint32_t pairs_per_thread, uint64_t* mismatches_dev,
                                  void* stream);
+
+/* ---- profiling hook ----------------------------------------------------------------------
+ * lq_fq_scale_grad / lq_fq_fwd_bwd_fused are two launches (traversal, finalize).  To time the traversal kernel ALONE with
+ * events from outside (bench.py's roofline leg), lq_profile_mark(event) makes every such call of THIS host thread record
+ * `event` (a hipEvent_t) on its stream between the two launches; lq_profile_mark(NULL) switches it off.  Nothing is
+ * recorded when a call needs no finalize launch (direct emit).                                                     */
+int lq_profile_mark(void* event);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("LQ_HIP_LIB") or os.path.join(_HERE, "csrc", "liblq_hi
 
 LQ_Q_NONE, LQ_Q_F32, LQ_Q_I32, LQ_Q_I8 = 0, 1, 2, 3
 LQ_ADAM_KERAS, LQ_ADAM_TORCH = 0, 1
+LQ_PENALTY_ACCUMULATE_DS = 0x100
 
 _c_i64 = ctypes.c_int64
 _c_f = ctypes.c_float
@@ -73,10 +74,11 @@ SIGNATURES.update({
     "lq_selftest_uniform_division": (_c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _c_p, _c_p]),
     "lq_q_minmax": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "lq_q_histogram": (_c_int, [_c_p, _c_p, ctypes.c_int32, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
+    "lq_profile_mark": (_c_int, [_c_p]),
 })
 
 _lib: Optional[ctypes.CDLL] = None
-_lock = threading.Lock()
+_lock = threading.RLock()
 
 
 class LQError(RuntimeError):
@@ -84,51 +86,65 @@ class LQError(RuntimeError):
 
 
 def load() -> ctypes.CDLL:
-    """Loads liblq_hip.so and binds every prototype.  Raises loudly if it is absent."""
-    global _lib
+    """Loads liblq_hip.so, binds every prototype and runs the device self-test.  Raises loudly if the library is absent;
+    a failed self-test is remembered and re-raised by EVERY later call (the library is never handed out unverified)."""
+    global _lib, _pending
+    if _selftest_error is not None:
+        raise RuntimeError(_selftest_error)
     if _lib is not None:
         return _lib
     with _lock:
+        if _selftest_error is not None:
+            raise RuntimeError(_selftest_error)
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"learned_quantization_amd: HIP extension not built ({LIB_PATH} missing). "
-                "Run `python -c 'import __graft_entry__ as g; g.build()'` or "
-                "`make -C learned_quantization_amd/csrc`.  There is no CPU fallback."
-            )
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (restype, argtypes) in SIGNATURES.items():
-            fn = getattr(lib, name)   # AttributeError here = ABI mismatch, also loud
-            fn.restype = restype
-            fn.argtypes = argtypes
-        _lib = lib
-        _device_selftest(lib)
-        return lib
+        lib = _pending
+        if lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"learned_quantization_amd: HIP extension not built ({LIB_PATH} missing). "
+                    "Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                    "`make -C learned_quantization_amd/csrc`.  There is no CPU fallback."
+                )
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (restype, argtypes) in SIGNATURES.items():
+                fn = getattr(lib, name)   # AttributeError here = ABI mismatch, also loud
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _pending = lib
+        if _device_selftest(lib):
+            _lib = lib                    # published only once the self-test has actually run and passed
+        return lib                        # test deferred (no GPU visible yet, or a stream capture is running): next call retries
 
 
-_selftested = False
+_pending: Optional[ctypes.CDLL] = None
+_selftest_error: Optional[str] = None
 
 
-def _device_selftest(lib) -> None:
-    """Once per process, on the first load with a GPU present: 2^24 random operand pairs through each of the two fast
-    division forms against the IEEE '/' ON THIS DEVICE.  The bit-exact-integer guarantee rests on them; a compiler
-    or hardware combination that ever disagrees must fail loudly, not quantise differently.  LQ_SKIP_SELFTEST=1 skips."""
-    global _selftested
-    if _selftested or os.environ.get("LQ_SKIP_SELFTEST") == "1" or not torch.cuda.is_available():
-        return
-    _selftested = True
+def _device_selftest(lib) -> bool:
+    """On the first load with a GPU present: 2^24 random operand pairs through each of the two fast division forms
+    against the IEEE '/' ON THIS DEVICE.  The bit-exact-integer guarantee rests on them; a compiler or hardware
+    combination that ever disagrees must fail loudly, not quantise differently.  Returns True when the test ran and passed
+    (or was waived with LQ_SKIP_SELFTEST=1), False when it has to be deferred; raises -- now and on every later load() --
+    when it failed."""
+    global _selftest_error
+    if os.environ.get("LQ_SKIP_SELFTEST") == "1":
+        return True
+    if not torch.cuda.is_available():
+        return False
     if torch.cuda.is_current_stream_capturing():
-        return
+        return False                      # cannot synchronise inside a capture: deferred, not cancelled
     bad = torch.zeros(2, dtype=torch.int64, device="cuda")
     rc = lib.lq_selftest_ratio_division(0x5EED, 256, 256, bad.data_ptr(), None)
     rc |= lib.lq_selftest_uniform_division(0x5EED, 256, 256, bad.data_ptr() + 8, None)
     torch.cuda.synchronize()
     n_ratio, n_uniform = (int(v) for v in bad.tolist())
     if rc or n_ratio or n_uniform:
-        raise RuntimeError(f"learned_quantization_amd: device self-test failed (rc={rc}, ratio division mismatches={n_ratio}, "
+        _selftest_error = (f"learned_quantization_amd: device self-test failed (rc={rc}, ratio division mismatches={n_ratio}, "
                            f"uniform division mismatches={n_uniform}): the fast division forms do not reproduce IEEE fp32 "
                            "division on this device/compiler; refusing to run")
+        raise RuntimeError(_selftest_error)
+    return True
 
 
 def check(rc: int, what: str) -> None:

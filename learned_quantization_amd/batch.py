@@ -36,6 +36,7 @@ class FakeQuantBatch:
         layers = custom_layers_of(model_or_layers) if isinstance(model_or_layers, torch.nn.Module) else list(model_or_layers)
         self.layers = layers
         self._external_grads = False
+        self.defer_scale_grads = False       # exact data-parallel mode: backward skips ds, scale_grads_from_param_grads() follows
         self.entries: List[_Entry] = []
         for layer in layers:
             if isinstance(layer, _ConvBase):
@@ -118,15 +119,40 @@ class FakeQuantBatch:
             layer.__dict__["_q_pre"] = (None if ik is None else outs[ik], None if ib is None else outs[ib])
         return outs
 
+    # ------------------------------------------------------------------ exact data-parallel mode (ddp.py, mode B)
+    def scale_grads_from_param_grads(self):
+        """ds of every nested-quantization tensor from its parameter's CURRENT gradient, in two launches.  After the
+        data-parallel all-reduce ``P.grad`` is the global-batch dy (dP == dy, custom_layers.py:118), so this yields the
+        single-device large-batch scale gradient, identical on every rank."""
+        lib = _hip.load()
+        keep = []
+        for i, e in enumerate(self.entries):
+            g = e.param.grad
+            if g is None:
+                if e.nested.penalty_threshold is not None:
+                    raise RuntimeError("scale_grads_from_param_grads: a quantised parameter has no gradient")
+                self._ptrs[i] = None
+                continue
+            g = _hip.require_device_f32(g, "parameter gradient")
+            keep.append(g)
+            self._ptrs[i] = g.data_ptr()
+        _hip.check(lib.lq_batch_scale_grad(self._handle, self._ptrs, _hip.ptr(self.ws), self.ws.numel(),
+                                           _hip.stream_ptr(self.device)), "lq_batch_scale_grad")
+        for e in self.entries:
+            if e.nested.penalty_threshold is not None:
+                e.nested.scale.grad = e.ds
+
     # ------------------------------------------------------------------ custom loss terms
     _KINDS = {"maxbin": 0, "difference": 1, "inverse": 2}
 
-    def inject_penalty_grads(self, kind: str, penalty_rate: float):
+    def inject_penalty_grads(self, kind: str, penalty_rate: float, accumulate_ds: bool = False):
         """Adds d(penalty_rate * penalty)/dP to every ``P.grad`` and writes d(...)/ds to every ``scale.grad`` in 2-4
         launches.  Call after ``loss.backward()`` of the task loss alone: the reference's objective is
         ``mean(SCCE) + penalty_rate * penalty`` (custom_loss_functions.py:58), so the coefficient of tensor i's term
         ``mean(...)_i`` is the constant ``penalty_rate * numel_i / sum(numel)`` (:110-116) and no autograd node per tensor
-        is needed.  Equivalent to differentiating ``SCCE*.compute_total_loss`` (tests/test_gpu_batch.py)."""
+        is needed.  Equivalent to differentiating ``SCCE*.compute_total_loss`` (tests/test_gpu_batch.py).
+        ``accumulate_ds``: add the penalty's scale gradient to what the ds buffers already hold (nested-quantization layers
+        trained with a loss term: LQ_PENALTY_ACCUMULATE_DS)."""
         lib = _hip.load()
         n = len(self.entries)
         normalizer = float(sum(e.param.numel() for e in self.entries))
@@ -140,7 +166,8 @@ class FakeQuantBatch:
                 if not g.is_contiguous():
                     raise ValueError("parameter gradients must be contiguous")
                 grads[i] = g.data_ptr()
-        _hip.check(lib.lq_batch_penalty_grads(self._handle, self._KINDS[kind], coeff, grads, _hip.ptr(self.ws), self.ws.numel(),
+        kind_flag = self._KINDS[kind] | (_hip.LQ_PENALTY_ACCUMULATE_DS if accumulate_ds else 0)
+        _hip.check(lib.lq_batch_penalty_grads(self._handle, kind_flag, coeff, grads, _hip.ptr(self.ws), self.ws.numel(),
                                               _hip.stream_ptr(self.device)), "lq_batch_penalty_grads")
         for e in self.entries:
             e.nested.scale.grad = e.ds
@@ -167,6 +194,11 @@ class _BatchFn(torch.autograd.Function):
     def backward(ctx, *dys):
         batch: FakeQuantBatch = ctx.batch
         lib = _hip.load()
+        if batch.defer_scale_grads:          # dP == dy (custom_layers.py:118); ds follows after the all-reduce
+            grads = [None]
+            for e, d in zip(batch.entries, dys):
+                grads.extend((d if d is not None else torch.zeros_like(e.out), None))
+            return tuple(grads)
         keep = []
         for i, (e, d) in enumerate(zip(batch.entries, dys)):
             if d is None:

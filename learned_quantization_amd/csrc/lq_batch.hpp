@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
 }
 
 template <int OP, int BS = 64>     // BS = 256 when some group of the batch has more than 256 partials (host decides)
-__global__ __launch_bounds__(BS) void k_batch_finalize(const Task* __restrict__ tasks, int ntasks, uint32_t* ws) {
+__global__ __launch_bounds__(BS) void k_batch_finalize(const Task* __restrict__ tasks, int ntasks, uint32_t* ws, int accum = 0) {
     const int ti = find_task(tasks, ntasks, blockIdx.x, true);
     const Task& t = tasks[ti];
     Params p = t.p;
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(BS) void k_batch_finalize(const Task* __restrict__ 
     f.o0 = (OP == OP_MAXBIN_FWD) ? t.mb : t.ds;
     f.o1 = nullptr;
     f.o2 = (OP == OP_MAXBIN_FWD) ? t.ties : nullptr;
+    f.accum = accum;
     finalize_block_body<OP, BS>(p, f, (int64_t)(blockIdx.x - t.first_group));
 }
 
@@ -111,15 +112,15 @@ __global__ __launch_bounds__(BS) void k_batch_finalize(const Task* __restrict__ 
 //   maxbin   ds[g] = -((c/G) * mb[g]) / s[g]          (custom_loss_functions.py:92,110; reduce_max + RealDiv gradients)
 //   inverse  ds[g] = s[g] == 0 ? 0 : -((c/G) / s[g]) / s[g]                     (:252-255)
 __global__ __launch_bounds__(kBlock) void k_batch_penalty_ds(const Task* __restrict__ tasks, int ntasks, uint32_t total_groups, int kind,
-                                                             CoefPack cf) {
+                                                             CoefPack cf, int accum) {
     const uint32_t gg = blockIdx.x * kBlock + threadIdx.x;
     if (gg >= total_groups) return;
     const int ti = find_task(tasks, ntasks, gg, true);
     const Task& t = tasks[ti];
     const uint32_t g = gg - t.first_group;
     const float up = cf.c[ti], sg = t.p.s[g], G = (float)t.p.G;
-    if (kind == 0) t.ds[g] = -((up / G) * t.mb[g]) / sg;
-    else t.ds[g] = (sg == 0.0f) ? 0.0f : -((up / G) / sg) / sg;
+    const float v = (kind == 0) ? -((up / G) * t.mb[g]) / sg : ((sg == 0.0f) ? 0.0f : -((up / G) / sg) / sg);
+    t.ds[g] = accum ? t.ds[g] + v : v;
 }
 
 // K6 for every scale of the batch in one launch: block per tensor.

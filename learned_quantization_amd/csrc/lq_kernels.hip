@@ -43,6 +43,7 @@
 #include "lq_hip.h"
 
 #include "lq_batch.hpp"
+#include "lq_stream2.hpp"
 
 namespace lq {
 
@@ -118,6 +119,10 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
                 RB = ceil_div(outer * ceil_div(C, 256), 512);
                 RB = ceil_div(RB, 16) * 16;
                 if (RB > 128) RB = 128;
+                if (const char* e = getenv("LQ_TUNE_COL_RB")) {   // development knob (tools/): rows per block of the column tile
+                    const int v = atoi(e);
+                    if (v >= 8 && (double)outer * (double)C >= (double)kPeriodic4Min) RB = v;
+                }
             }
             if (RB > outer) RB = outer;
             if (!nby) nby = ceil_div(outer, RB);
@@ -182,6 +187,7 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
 }
 
 static thread_local char g_err[512] = "";
+static thread_local hipEvent_t g_mark = nullptr;      // lq_profile_mark
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -251,9 +257,139 @@ static void col_variant(const Plan& pl, const void* P, const void* dy, const voi
     }
 }
 
+// development knob: LQ_TUNE_S2 = bit mask of round-2 streaming forms to DISABLE (1 flat K1, 2 pipelined column tile,
+// 4 pipelined periodic columns, 8 tiny-row passes); LQ_TUNE_PIPE = "U,NW" of the column tile; LQ_TUNE_TINY_U = passes
+static int tune_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// Streaming-size (>= 4 M elements) forms of lq_stream2.hpp.  Returns 1 when it launched the traversal, 0 when the
+// round-1 traversal should run, < 0 on error.
+template <int OP>
+static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st);
+
+template <int OP>
+static int launch_stream2(Plan& pl, const Params& p, hipStream_t st) {
+    if constexpr (OP == OP_FWD || OP == OP_BWD || OP == OP_FUSED) return launch_stream2_impl<OP>(pl, p, st);
+    else return 0;
+}
+
+template <int OP>
+static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
+    using O = OpT<OP>;
+    const double numel = (double)p.outer * (double)p.G * (double)p.inner;
+    if (numel < (double)kPeriodic4Min || pl.mode == MODE_ROW_BIG) return 0;
+    const bool al16 = aligned(p.P, 16) && (!O::kDy || aligned(p.dy, 16)) && (!O::kStore || aligned(p.out, 16));
+    if (!al16) return 0;
+    static const int off = tune_int("LQ_TUNE_S2", 0);
+    const bool nt = numel * 4.0 >= (double)kNtBytes;
+    const int64_t n = p.outer * p.G * p.inner;
+    // ---- K1 as a flat stream: whenever a float4 has one group (inner % 4 == 0) -- tiny rows, rows of 8..1020 elements,
+    // column matrices with inner = 4, 8, 12
+    if constexpr (OP == OP_FWD) {
+        const bool one_group = p.inner % 4 == 0;                                             // a float4 never straddles groups
+        const bool scale4 = p.inner == 1 && p.G % 4 == 0 && aligned(p.s, 16) && !(off & 32);   // its 4 scales are one float4
+        if (!(off & 1) && (one_group || scale4)) {
+            const int64_t nv = n >> 2;
+            const int64_t blocks = ceil_div(nv, 512);
+            if (blocks <= 2147483647ll) {
+                const bool wide = n >= 4294967296ll;
+#define LQ_FLAT(NT_, GM_) hipLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, p, nv, 0)
+                if (one_group) {
+                    if (nt) {
+                        if (wide) LQ_FLAT(1, 2); else LQ_FLAT(1, 0);
+                    } else {
+                        if (wide) LQ_FLAT(0, 2); else LQ_FLAT(0, 0);
+                    }
+                } else {
+                    if (nt) {
+                        if (wide) LQ_FLAT(1, 5); else LQ_FLAT(1, 4);
+                    } else {
+                        if (wide) LQ_FLAT(0, 5); else LQ_FLAT(0, 4);
+                    }
+                }
+#undef LQ_FLAT
+                return check_hip("flat forward launch") ? -1 : 1;
+            }
+        }
+    }
+    if (pl.mode == MODE_COL) {
+        constexpr int kUp = (OP == OP_FWD) ? 4 : 2;            // float4 per stream in flight: one stream wants 4, two streams 2
+        if (pl.C <= 64) {
+            if ((off & 4) || !pl.per4) return 0;
+            static const int per = tune_int("LQ_TUNE_PERIODIC", 0);      // development knob: U*10 + (block size / 256)
+            if (nt && (per == 12 || per == 22)) {
+                // 512-thread blocks, half as many: the finalize that follows must walk the partial layout this launch produces
+                const int64_t nb2 = ((pl.ysplit / 2) / pl.C) * pl.C;
+                if (nb2 >= pl.C) {
+                    pl.ysplit = nb2;
+                    pl.np = nb2 * pl.C;
+                    pl.n1 = nb2;
+                    if (per == 12) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1, 512>), dim3((unsigned)nb2), dim3(512), 0, st, p, (int)pl.C, nb2);
+                    else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 2, 512>), dim3((unsigned)nb2), dim3(512), 0, st, p, (int)pl.C, nb2);
+                    return check_hip("periodic column launch") ? -1 : 1;
+                }
+            }
+            if (nt && per == 11) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1, 256>), dim3((unsigned)pl.ysplit), dim3(256), 0, st, p, (int)pl.C, pl.ysplit);
+            else if (nt) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
+            else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
+            return check_hip("periodic column launch") ? -1 : 1;
+        }
+        if ((off & 2) || pl.C % 4 != 0) return 0;
+        const int64_t nbx = ceil_div(pl.C, 256);
+        const int64_t blocks = nbx * pl.ysplit;
+        if (blocks > 2147483647ll) return 0;
+        static const int pipe_r = tune_int("LQ_TUNE_PIPE", 24);      // U*10 + NW (scale-gradient ops)
+        static const int pipe_f = tune_int("LQ_TUNE_PIPE_FWD", 24);
+        const int pipe = (OP == OP_FWD) ? pipe_f : pipe_r;
+#define LQ_PIPE(NT_, U_, NW_) hipLaunchKernelGGL((k_col_pipe<OP, NT_, U_, NW_>), dim3((unsigned)blocks), dim3(NW_ * 64), 0, st, p, pl.C, pl.rps, nbx)
+        if (nt) {
+            if (pipe == 14) LQ_PIPE(1, 1, 4); else if (pipe == 44) LQ_PIPE(1, 4, 4); else if (pipe == 28) LQ_PIPE(1, 2, 8);
+            else if (pipe == 18) LQ_PIPE(1, 1, 8); else if (pipe == 48) LQ_PIPE(1, 4, 8); else LQ_PIPE(1, 2, 4);
+        } else {
+            LQ_PIPE(0, 2, 4);
+        }
+#undef LQ_PIPE
+        return check_hip("pipelined column launch") ? -1 : 1;
+    }
+    if constexpr (OP == OP_FWD) {
+        return 0;                                      // row-small forward whose float4s straddle groups: cannot happen (L % 4 == 0 there)
+    } else {
+        // MODE_ROW_SMALL, scale-gradient ops: tiny rows
+        if ((off & 8) || pl.L > 64 || pl.L < 8 || pl.L % 4 != 0) return 0;
+        const int lg = row_small_lpr_log2_vec(pl.L);         // 1..4
+        static const int tiny_u = tune_int("LQ_TUNE_TINY_U", 2);
+        int U = (1 << lg) < tiny_u ? (1 << lg) : tiny_u;
+        if (U != 2 && U != 4) U = 2;
+        const int64_t rows_per_block = (int64_t)kWavesPerBlock * (64 >> lg) * U;
+        const int64_t blocks = ceil_div(pl.R, rows_per_block);
+        if (blocks > 2147483647ll) return 0;
+        const int gm = (p.outer == 1) ? 0 : (pl.R < 4294967296ll ? 1 : 2);
+#define LQ_TINY3(NT_, U_, LG_) do { \
+            if (gm == 0) hipLaunchKernelGGL((k_row_tiny<OP, NT_, U_, LG_, 0>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L); \
+            else if (gm == 1) hipLaunchKernelGGL((k_row_tiny<OP, NT_, U_, LG_, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L); \
+            else hipLaunchKernelGGL((k_row_tiny<OP, NT_, U_, LG_, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L); } while (0)
+#define LQ_TINY2(NT_) do { \
+            if (lg == 1) LQ_TINY3(NT_, 2, 1); \
+            else if (lg == 2) { if (U == 2) LQ_TINY3(NT_, 2, 2); else LQ_TINY3(NT_, 4, 2); } \
+            else if (lg == 3) { if (U == 2) LQ_TINY3(NT_, 2, 3); else LQ_TINY3(NT_, 4, 3); } \
+            else { if (U == 2) LQ_TINY3(NT_, 2, 4); else LQ_TINY3(NT_, 4, 4); } } while (0)
+        if (nt) LQ_TINY2(1); else LQ_TINY2(0);
+#undef LQ_TINY2
+#undef LQ_TINY3
+        return check_hip("tiny-row launch") ? -1 : 1;
+    }
+}
+
 template <int OP>
 static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
     using O = OpT<OP>;
+    {
+        const int r2 = launch_stream2<OP>(pl, p, st);
+        if (r2 < 0) return LQ_EHIP;
+        if (r2 > 0) return LQ_OK;
+    }
     if (pl.mode == MODE_ROW_BIG) {
         const int64_t units = pl.R * pl.nc;
         if (units > 2147483647ll) return fail(LQ_EINVAL, "too many work units (%lld)", (long long)units);
@@ -324,6 +460,7 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
 template <int OP>
 static int launch_finalize(const Params& p, FinGeom f, hipStream_t st) {
     const int64_t n = f.n1 * f.n2;
+    if (g_mark) (void)hipEventRecord(g_mark, st);
     // one thread per group walks its partials one after the other: right for very many groups (throughput) or a handful of
     // partials, a latency trap otherwise (32 partials: ~10 us) -- few groups get one wave each instead
     if (n <= 4 || (n <= 32 && f.groups >= 2048)) {
@@ -386,6 +523,11 @@ using namespace lq;
 extern "C" {
 
 int lq_version(void) { return LQ_ABI_VERSION; }
+
+int lq_profile_mark(void* event) {
+    g_mark = (hipEvent_t)event;
+    return LQ_OK;
+}
 
 const char* lq_last_error(void) { return g_err; }
 
@@ -867,16 +1009,18 @@ int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, siz
     if (rc) return rc;
     if (batch_wide_finalize(b->bwd_h))
         hipLaunchKernelGGL((k_batch_finalize<OP_BWD, 256>), dim3(b->bwd_groups), dim3(256), 0, (hipStream_t)stream, b->bwd_d,
-                           (int)b->bwd_h.size(), (uint32_t*)ws);
+                           (int)b->bwd_h.size(), (uint32_t*)ws, 0);
     else
         hipLaunchKernelGGL((k_batch_finalize<OP_BWD>), dim3(b->bwd_groups), dim3(64), 0, (hipStream_t)stream, b->bwd_d,
-                           (int)b->bwd_h.size(), (uint32_t*)ws);
+                           (int)b->bwd_h.size(), (uint32_t*)ws, 0);
     return check_hip("batch finalize launch");
 }
 
 int lq_batch_penalty_grads(const lq_batch* b, int kind, const float* coeff, float* const* grad, void* ws, size_t ws_bytes,
                            void* stream) {
     if (!b) return fail(LQ_EINVAL, "lq_batch_penalty_grads: NULL batch");
+    const int accum = (kind & LQ_PENALTY_ACCUMULATE_DS) ? 1 : 0;
+    kind &= ~LQ_PENALTY_ACCUMULATE_DS;
     if (kind < LQ_PENALTY_MAXBIN || kind > LQ_PENALTY_INVERSE) return fail(LQ_EINVAL, "lq_batch_penalty_grads: bad kind %d", kind);
     if (!coeff) return fail(LQ_EINVAL, "lq_batch_penalty_grads: coeff is NULL");
     if (b->pen_h.size() != (size_t)b->n) return fail(LQ_EINVAL, "lq_batch_penalty_grads: every tensor of the batch needs a ds buffer");
@@ -904,14 +1048,14 @@ int lq_batch_penalty_grads(const lq_batch* b, int kind, const float* coeff, floa
         PtrPack none;
         memset(&none, 0, sizeof(none));
         hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_FWD>), dim3(b->pen_blocks), dim3(kBlock), 0, st, b->pen_d, nt, (uint32_t*)ws, none, 0, cf);
-        hipLaunchKernelGGL((k_batch_finalize<OP_MAXBIN_FWD>), dim3(b->pen_groups), dim3(64), 0, st, b->pen_d, nt, (uint32_t*)ws);
+        hipLaunchKernelGGL((k_batch_finalize<OP_MAXBIN_FWD>), dim3(b->pen_groups), dim3(64), 0, st, b->pen_d, nt, (uint32_t*)ws, 0);
         hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_BWD>), dim3(b->pen_blocks), dim3(kBlock), 0, st, b->pen_d, nt, (uint32_t*)ws, pk, 2, cf);
-        hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(b->pen_groups, kBlock)), dim3(kBlock), 0, st, b->pen_d, nt, b->pen_groups, 0, cf);
+        hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(b->pen_groups, kBlock)), dim3(kBlock), 0, st, b->pen_d, nt, b->pen_groups, 0, cf, accum);
     } else if (kind == LQ_PENALTY_DIFFERENCE) {
         hipLaunchKernelGGL((k_batch_traverse<OP_DIFF_BWD>), dim3(b->pen_blocks), dim3(kBlock), 0, st, b->pen_d, nt, (uint32_t*)ws, pk, 2, cf);
-        hipLaunchKernelGGL((k_batch_finalize<OP_DIFF_BWD>), dim3(b->pen_groups), dim3(64), 0, st, b->pen_d, nt, (uint32_t*)ws);
+        hipLaunchKernelGGL((k_batch_finalize<OP_DIFF_BWD>), dim3(b->pen_groups), dim3(64), 0, st, b->pen_d, nt, (uint32_t*)ws, accum);
     } else {
-        hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(b->pen_groups, kBlock)), dim3(kBlock), 0, st, b->pen_d, nt, b->pen_groups, 2, cf);
+        hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(b->pen_groups, kBlock)), dim3(kBlock), 0, st, b->pen_d, nt, b->pen_groups, 2, cf, accum);
     }
     return check_hip("batch penalty launch");
 }

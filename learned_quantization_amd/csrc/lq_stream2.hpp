@@ -1,0 +1,369 @@
+// lq_stream2.hpp -- streaming-size (>= 4 M elements) forms of the column and tiny-row traversals (round 2)
+//
+// What rocprofv3 showed for the round-1 kernels of these modes (profiles/r02/shapes_baseline.json; MI355X):
+//   * every kernel moves exactly its algorithmic bytes (traffic / algorithmic <= 1.03): nothing is re-read;
+//   * the read-only K2 tile already streams at 5.6-5.7 TB/s, but the SAME loop with stores in it (K1: 5.0, K4: 4.9 TB/s)
+//     is a fifth slower.  On gfx9-family hardware loads and stores share one in-order counter (vmcnt): a wave that
+//     issues the stores of iteration i and then the loads of iteration i+1 cannot see those loads before the stores
+//     have been acknowledged by the memory side, so every iteration pays write latency + read latency back to back;
+//   * tiny rows (1 M rows x 32): K2 60 us against 47 us for the same bytes in rows of 512 -- the per-row epilogue (team
+//     reduction through ds_bpermute, f64 mean, direct emit from 8 of 64 lanes) is paid once per 128 bytes of each stream.
+// Hence:
+//   k_flat_fwd        K1 (no reduction) of ANY descriptor as a flat stream, one float4 per thread and no loop -- the shape
+//                     of the row-stream kernel; the group of an element comes from its flat index (32-bit arithmetic).
+//   k_col_pipe        column tile with a software pipeline: the loads of iteration i+1 are issued BEFORE the stores of
+//                     iteration i, so the vmcnt wait that covers them does not include those stores.
+//   k_col_periodic_pipe   the same pipeline for the periodic float4 form (C <= 64).
+//   k_row_tiny        rows of <= 64 elements: U passes of rows per wave with all loads up front, DPP team reductions
+//                     (VALU only), ONE emit per wave in which lane (team, u) finishes row (u, team).
+// All of them are used for tensors of >= 4 M elements only (kPeriodic4Min): below that the round-1 bodies run, the same
+// code the multi-tensor batch kernels inline, so batched and single-tensor results stay bit-identical there.
+#ifndef LQ_STREAM2_HPP_
+#define LQ_STREAM2_HPP_
+#include "lq_traverse.hpp"
+
+namespace lq {
+
+// ------------------------------------------------------------------------------------------
+//  K1 as a flat stream.  GM: how the group of element i is found
+//     0: g = (i / inner) % G with 32-bit arithmetic (numel < 2^32), one group per float4 (inner % 4 == 0)
+//     1: the same, per element (a float4 may straddle groups)
+//     2 / 3: as 0 / 1 with 64-bit arithmetic
+//     4 / 5: inner == 1 and G % 4 == 0 (NHWC per-channel activations, column-wise Dense): the four scales of a float4 are
+//            one aligned float4 of the scale vector at column (i % G) -- one 32-bit (4) or 64-bit (5) modulo per thread;
+//            the quotient is the IEEE `/` itself (correctly rounded, ~11 VALU each): building four reciprocal contexts
+//            per thread costs more than it saves when each is used for a single element
+// ------------------------------------------------------------------------------------------
+template <int GM>
+__device__ __forceinline__ int64_t flat_group(const Params& p, int64_t i) {
+    if (GM >= 2) return (i / p.inner) % p.G;
+    const uint32_t q = (uint32_t)i / (uint32_t)p.inner;
+    return (int64_t)(q % (uint32_t)p.G);
+}
+
+template <int OP, int BS, int NT, int GM>
+__global__ __launch_bounds__(BS) void k_flat_fwd(Params p, int64_t nv, int rem) {
+    using O = OpT<OP>;
+    const int64_t v = (int64_t)blockIdx.x * BS + threadIdx.x;
+    if (v < nv) {
+        const int64_t i = v * 4;
+        const float4 x = load4<NT>(p.P + i);
+        __builtin_amdgcn_sched_barrier(0);      // the load first; index arithmetic and contexts while it is in flight
+        Acc none = O::template init<Acc>();
+        float4 o;
+        if (GM == 4 || GM == 5) {
+            const int64_t c = GM == 4 ? (int64_t)((uint32_t)i % (uint32_t)p.G) : i % p.G;
+            const float4 sv = *reinterpret_cast<const float4*>(p.s + c);
+            float4 q;
+            q.x = floorf(x.x / sv.x); q.y = floorf(x.y / sv.y); q.z = floorf(x.z / sv.z); q.w = floorf(x.w / sv.w);   // custom_layers.py:56-59
+            o.x = q.x * sv.x; o.y = q.y * sv.y; o.z = q.z * sv.z; o.w = q.w * sv.w;                                   // :60
+            if (p.q) {
+                store_q(p.q, p.q_dtype, i + 0, q.x);
+                store_q(p.q, p.q_dtype, i + 1, q.y);
+                store_q(p.q, p.q_dtype, i + 2, q.z);
+                store_q(p.q, p.q_dtype, i + 3, q.w);
+            }
+        } else if (GM == 0 || GM == 2) {
+            const Ctx ctx = O::ctx(p, flat_group<GM>(p, i));
+            o = O::elem4(p, ctx, i, x, x, none);
+        } else {
+            Ctx ctx[4];
+            Acc acc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ctx[k] = O::ctx(p, flat_group<GM>(p, i + k));
+                acc[k] = none;
+            }
+            o = O::elem4c(p, ctx, i, x, x, acc);
+        }
+        if (O::kStore) store4<NT>(p.out + i, o);
+    } else if (v == nv && rem) {                // numel % 4 trailing elements
+        Acc none = O::template init<Acc>();
+        for (int k = 0; k < rem; ++k) {
+            const int64_t i = nv * 4 + k;
+            const Ctx ctx = O::ctx(p, flat_group<(GM | 1)>(p, i));
+            const float r = O::elem(p, ctx, i, p.P[i], 0.f, none);
+            if (O::kStore) p.out[i] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Column tile, software-pipelined.  Block of NW waves owns RB rows x 256 columns; a lane keeps 4 fixed columns; wave w
+//  walks rows w, w + NW, ...; U rows per iteration and stream.  Partial layout as in col_tile_body: (row-block, column).
+// ------------------------------------------------------------------------------------------
+template <int OP, int NT, int U, int NW>
+__global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64_t RB, int64_t nbx) {
+    using O = OpT<OP>;
+    __shared__ Acc lds[O::kReduce ? NW * 256 : 1];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t b = blockIdx.x;
+    const int64_t by = b / nbx, bx = b - by * nbx;
+    const int64_t col0 = (bx * 64 + lane) * 4;
+    const bool active = col0 < C;            // C % 4 == 0: a float4 never straddles a row end
+    const int64_t r0 = by * RB;
+    const int64_t r1 = (r0 + RB < p.outer) ? r0 + RB : p.outer;
+    Acc acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = O::template init<Acc>();
+    if (active && r0 + w < r1) {
+        const int64_t step = (int64_t)NW * C;                 // elements between consecutive rows of this wave
+        int64_t i0 = (r0 + w) * C + col0;                     // element index of this lane's float4 in the wave's next row
+        const int cnt = (int)((r1 - (r0 + w) + NW - 1) / NW); // rows of this wave (wave-uniform)
+        const int groups = cnt / U;                           // complete groups of U rows: the pipelined part
+        float4 xa[U], da[U], xb[U], db[U];
+        if (groups > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xa[u] = load4<NT>(p.P + i0 + u * step);
+                da[u] = xa[u];
+                if (O::kDy) da[u] = load4<NT>(p.dy + i0 + u * step);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Ctx ctx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ctx[k] = O::ctx(p, (col0 + k) / p.inner);
+        // One phase: issue the loads of the NEXT group into (xn, dn), then compute and store the current group (xc, dc).
+        // The two register sets swap roles every phase (the loop is unrolled twice): copying "next" into "current"
+        // would make the compiler wait for the loads -- and, vmcnt being in-order, for the stores before them -- at
+        // the copy instead of at the first use one phase later.  Every loaded group is consumed on every path (no
+        // per-row validity inside the loop), so no wait is carried around the back edge.
+        int g = 0;
+        auto phase = [&](float4 (&xc)[U], float4 (&dc)[U], float4 (&xn)[U], float4 (&dn)[U]) -> bool {
+            const bool more = g + 1 < groups;                 // wave-uniform
+            if (more) {
+                const int64_t in0 = i0 + U * step;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    xn[u] = load4<NT>(p.P + in0 + u * step);
+                    dn[u] = xn[u];
+                    if (O::kDy) dn[u] = load4<NT>(p.dy + in0 + u * step);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                // the next group's loads stay ahead of this phase's stores
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + u * step;
+                const float4 ov = O::elem4c(p, ctx, i, xc[u], dc[u], acc);
+                if (O::kStore) store4<NT>(p.out + i, ov);
+            }
+            ++g;
+            i0 += U * step;
+            return more;
+        };
+        if (groups > 0) {
+            for (;;) {
+                if (!phase(xa, da, xb, db)) break;
+                if (!phase(xb, db, xa, da)) break;
+            }
+        }
+        for (int t = groups * U; t < cnt; ++t) {              // at most U - 1 leftover rows
+            const float4 x = load4<NT>(p.P + i0);
+            float4 d = x;
+            if (O::kDy) d = load4<NT>(p.dy + i0);
+            const float4 ov = O::elem4c(p, ctx, i0, x, d, acc);
+            if (O::kStore) store4<NT>(p.out + i0, ov);
+            i0 += step;
+        }
+    }
+    if (O::kReduce) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds[w * 256 + lane * 4 + k] = acc[k];
+        __syncthreads();
+        if (w == 0 && active) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Acc r = lds[lane * 4 + k];
+#pragma unroll
+                for (int ww = 1; ww < NW; ++ww) O::merge(r, lds[ww * 256 + lane * 4 + k]);   // fixed wave order
+                write_partial_t<OP>(p, by * C + col0 + k, r);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Periodic float4 form (C <= 64), software-pipelined.  Geometry and partial layout of col_periodic4_body: `nblk` (a
+//  multiple of C) blocks of 256 threads; thread tid sees vectors tid, tid + T, ...; one partial per (block, column).
+// ------------------------------------------------------------------------------------------
+template <int OP, int NT, int U, int BS = kBlock>
+__global__ __launch_bounds__(BS) void k_col_periodic_pipe(Params p, int C, int64_t nblk) {
+    using O = OpT<OP>;
+    __shared__ Acc lds[O::kReduce ? BS * 5 : 1];
+    const int64_t blk = blockIdx.x;
+    const int64_t numel = p.outer * (int64_t)C;
+    const int64_t T = nblk * BS;
+    const int64_t tid = blk * BS + threadIdx.x;
+    const int64_t nv = numel >> 2;
+    Acc acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = O::template init<Acc>();
+    const int c0 = (int)((tid * 4) % C);
+    // every thread owns at least nv / T vectors (threads below nv % T one more): the pipelined part runs over the groups
+    // of U vectors that EVERY thread has -- no per-lane validity inside the loop (see k_col_pipe) -- the rest follows
+    const int64_t common = nv / T;
+    const int64_t groups = common / U;
+    int64_t v = tid;
+    float4 xa[U], da[U], xb[U], db[U];
+    if (groups > 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xa[u] = load4<NT>(p.P + (v + u * T) * 4);
+            da[u] = xa[u];
+            if (O::kDy) da[u] = load4<NT>(p.dy + (v + u * T) * 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);          // the first loads before the scale fetches
+    Ctx ctx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ctx[j] = O::ctx(p, ((c0 + j) % C) / p.inner);
+    if (groups > 0) {
+        int64_t g = 0;
+        auto phase = [&](float4 (&xc)[U], float4 (&dc)[U], float4 (&xn)[U], float4 (&dn)[U]) -> bool {
+            const bool more = g + 1 < groups;                 // grid-uniform
+            const int64_t vn = v + (int64_t)U * T;
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    xn[u] = load4<NT>(p.P + (vn + u * T) * 4);
+                    dn[u] = xn[u];
+                    if (O::kDy) dn[u] = load4<NT>(p.dy + (vn + u * T) * 4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = (v + u * T) * 4;
+                const float4 o = O::elem4c(p, ctx, i, xc[u], dc[u], acc);
+                if (O::kStore) store4<NT>(p.out + i, o);
+            }
+            v = vn;
+            ++g;
+            return more;
+        };
+        for (;;) {
+            if (!phase(xa, da, xb, db)) break;
+            if (!phase(xb, db, xa, da)) break;
+        }
+    }
+    for (; v < nv; v += T) {                                  // at most U leftover vectors of this thread
+        const float4 x = load4<NT>(p.P + v * 4);
+        float4 d = x;
+        if (O::kDy) d = load4<NT>(p.dy + v * 4);
+        const float4 o = O::elem4c(p, ctx, v * 4, x, d, acc);
+        if (O::kStore) store4<NT>(p.out + v * 4, o);
+    }
+    const int rem = (int)(numel & 3);
+    if (rem && tid == nv % T) {                     // ragged tail: the thread that would own the next vector
+        const int64_t i = nv * 4;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j < rem) {
+                const float o = O::elem(p, ctx[j], i + j, p.P[i + j], O::kDy ? p.dy[i + j] : 0.f, acc[j]);
+                if (O::kStore) p.out[i + j] = o;
+            }
+        }
+    }
+    if (O::kReduce) {
+        Acc* lds2 = lds + BS * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[threadIdx.x * 4 + j] = acc[j];
+        __syncthreads();
+        // entry e of this block belongs to column (blk*BS*4 + e) % C; H helpers per column walk them in a fixed order
+        const int H = BS / C;
+        const int c = (int)threadIdx.x % C, h = (int)threadIdx.x / C;
+        const int b0 = (int)((blk * (BS * 4)) % C);
+        if (h < H) {
+            int e0 = c - b0;
+            if (e0 < 0) e0 += C;
+            Acc r = O::template init<Acc>();
+            for (int e = e0 + h * C; e < BS * 4; e += H * C) O::merge(r, lds[e]);
+            lds2[h * C + c] = r;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            Acc r = lds2[threadIdx.x];
+            for (int hh = 1; hh < H; ++hh) O::merge(r, lds2[hh * C + (int)threadIdx.x]);                  // fixed order
+            write_partial_t<OP>(p, blk * C + threadIdx.x, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Tiny rows (L <= 64, L % 4 == 0, 16-B aligned bases): a team of lpr = 2^lg <= 16 lanes owns a row (one float4 per
+//  lane), a wave takes U passes of 64/lpr consecutive rows with every load issued up front, reduces the U teams'
+//  accumulators with DPP (every lane of a team ends with the team total), and then lane (team, u), u < U <= lpr,
+//  finishes row (u, team): ONE emit / partial store per wave for U * 64/lpr rows.
+//  GM: 0 -> g = row (outer == 1), 1 -> 32-bit row % G, 2 -> 64-bit.
+// ------------------------------------------------------------------------------------------
+template <int STEPS>
+__device__ __forceinline__ void dpp_team_reduce(Acc& acc) {      // team of 2^STEPS lanes inside a 16-lane DPP row
+    if (STEPS >= 1) dpp_step<0xB1, 0xf>(acc);     // quad_perm [1,0,3,2]
+    if (STEPS >= 2) dpp_step<0x4E, 0xf>(acc);     // quad_perm [2,3,0,1]
+    if (STEPS >= 3) dpp_step<0x141, 0xf>(acc);    // row_half_mirror
+    if (STEPS >= 4) dpp_step<0x140, 0xf>(acc);    // row_mirror
+}
+
+template <int OP, int NT, int U, int LG, int GM>
+__global__ __launch_bounds__(kBlock) void k_row_tiny(Params p, int64_t R, int L) {
+    using O = OpT<OP>;
+    constexpr int lpr = 1 << LG, tpw = 64 >> LG;       // lanes per row, rows per wave and pass
+    static_assert(U <= lpr, "one finishing lane per (team, pass)");
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int team = lane >> LG, li = lane & (lpr - 1);
+    const int L4 = L >> 2;
+    const int64_t wave_base = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * (tpw * U);
+    if (wave_base >= R) return;                        // wave-uniform
+    const int lic = li < L4 ? li : 0;
+    float4 x[U], d[U];
+    int64_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        row[u] = wave_base + u * tpw + team;
+        const int64_t rr = row[u] < R ? row[u] : R - 1;      // clamp: the loads stay unconditional
+        const int64_t i = rr * (int64_t)L + lic * 4;
+        x[u] = load4<NT>(p.P + i);
+        d[u] = x[u];
+        if (O::kDy) d[u] = load4<NT>(p.dy + i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Acc acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        acc[u] = O::template init<Acc>();
+        if (row[u] < R && li < L4) {
+            const int64_t g = GM == 0 ? row[u] : (GM == 1 ? (int64_t)((uint32_t)row[u] % (uint32_t)p.G) : row[u] % p.G);
+            const Ctx ctx = O::ctx(p, g);
+            const int64_t i = row[u] * (int64_t)L + li * 4;
+            const float4 r = O::elem4(p, ctx, i, x[u], d[u], acc[u]);
+            if (O::kStore) store4<NT>(p.out + i, r);
+        }
+    }
+    if (O::kReduce) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) dpp_team_reduce<LG>(acc[u]);
+        Acc mine = acc[0];
+#pragma unroll
+        for (int u = 1; u < U; ++u)
+            if (li == u) mine = acc[u];
+        const int64_t myrow = wave_base + li * tpw + team;
+        if (li < U && myrow < R) {
+            int64_t idx;
+            if (GM == 0) {
+                idx = myrow;                            // outer == 1: partial index == row == group
+            } else {
+                const int64_t o = GM == 1 ? (int64_t)((uint32_t)myrow / (uint32_t)p.G) : myrow / p.G;
+                const int64_t g = myrow - o * p.G;
+                idx = g * p.outer + o;                  // group-major partials (see row_small_body); direct emit has outer == 1
+            }
+            write_partial_t<OP>(p, idx, mine);
+        }
+    }
+}
+
+}  // namespace lq
+
+#endif

@@ -485,6 +485,7 @@ struct FinGeom {
     float* o0;           // op-specific outputs
     float* o1;
     uint32_t* o2;
+    int accum;           // OP_DIFF_BWD: add to o0 instead of overwriting (LQ_PENALTY_ACCUMULATE_DS)
 };
 
 template <int OP>
@@ -529,7 +530,8 @@ struct FinT<OP_DIFF_FWD> {
 template <>
 struct FinT<OP_DIFF_BWD> {
     __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
-        f.o0[g] = (float)a.c;
+        const float v = (float)a.c;
+        f.o0[g] = f.accum ? f.o0[g] + v : v;
     }
 };
 
@@ -542,6 +544,7 @@ __device__ __forceinline__ void emit_direct(const Params& p, int64_t g, const Ac
     f.o0 = p.e0;
     f.o1 = p.e1;
     f.o2 = nullptr;
+    f.accum = 0;
     AccW w;
     w.a = acc.a;
     w.b = (double)acc.b;

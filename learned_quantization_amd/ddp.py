@@ -74,6 +74,14 @@ class GradBucket:
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+def _avg_op(group=None):
+    """RCCL averages inside the collective (ReduceOp.AVG); gloo has no AVG: pre-divide and SUM there."""
+    try:
+        return dist.ReduceOp.AVG if dist.get_backend(group) == "nccl" else None
+    except Exception:
+        return None
+
+
 class DataParallel:
     """Wraps a module for data-parallel training.
 
@@ -82,34 +90,57 @@ class DataParallel:
     The flat bucket is cut into sub-buckets of ``bucket_mb`` MiB in reverse parameter order; a sub-bucket's
     all-reduce is launched (asynchronously, RCCL's own stream) from a post-accumulate-grad hook as soon as every
     parameter in it has its gradient, so the exchange of the late layers overlaps the backward of the early ones.
-    ``sync_gradients`` launches whatever is left and waits.  ``overlap=False`` = one all-reduce after backward.
+    ``sync_gradients`` launches whatever is left and waits.  ``overlap=False`` = one all-reduce per sub-bucket after
+    backward.  On RCCL the mean is taken by the collective itself (``ReduceOp.AVG``: no extra launch per bucket).
+
+    One backward per ``zero_grad()`` -- the reference's training loop.  For gradient accumulation run the earlier
+    backward passes under ``with dp.no_sync():`` (gradients accumulate in the bucket, nothing is exchanged); a second
+    backward that would hit an already exchanged bucket raises instead of silently leaving the replicas diverged.
+
+    With the multi-tensor batch (``FakeQuantBatch``) every dP flows through ONE autograd node at the very end of the
+    backward pass, so buckets that hold quantised parameters or scales complete last and nothing of their exchange
+    overlaps; buckets of the ordinary layers (BN, plain Dense) still do.
+
+    mode "B": the nested layers are told to skip their local scale gradient in backward (it would be discarded);
+    ``sync_gradients`` recomputes every ds from the all-reduced P.grad -- through ``batch.scale_grads_from_param_grads()``
+    (two launches for all tensors) when a ``FakeQuantBatch`` is attached with ``attach_batch``, else tensor by tensor.
+
+    ``force_collectives=True`` runs the collectives even in a one-rank group (rehearsal of the RCCL path on one GPU).
     """
 
     def __init__(self, module: torch.nn.Module, mode: str = "A", group=None,
                  scale_grad_fn: Optional[Callable] = None, broadcast: bool = True, bucket_mb: float = 25.0,
-                 overlap: bool = True):
+                 overlap: bool = True, force_collectives: bool = False):
         if mode not in ("A", "B"):
             raise ValueError("mode must be 'A' or 'B'")
         self.module = module
         self.mode = mode
         self.group = group
         self._scale_grad_fn = scale_grad_fn
+        self._batch = None
         params = [p for p in module.parameters() if p.requires_grad]
         self.scales = [p for p in params if getattr(p, "lq_is_scale", False)]
         self.others = [p for p in params if not getattr(p, "lq_is_scale", False)]
         # mode B never communicates ds: scales stay outside the bucket
         self.bucket = GradBucket(params if mode == "A" else self.others)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if broadcast and dist.is_initialized() and self.world > 1:
+        self._collectives = dist.is_initialized() and (self.world > 1 or force_collectives)
+        self._avg = _avg_op(group) if self._collectives else None
+        if broadcast and dist.is_initialized() and self._collectives:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if mode == "B":
+            for _, nested in self._nq_pairs():
+                nested.defer_scale_grad = True        # backward skips the local K2+K3 launch (ops._NestedQuantFn)
         # ---- sub-buckets (contiguous ranges of the flat buffer), last parameters first
         self._ranges: List[Tuple[int, int]] = []
         self._param_bucket = {}
         self._pending_count: List[int] = []
         self._handles: List = []
         self._launched: List[bool] = []
-        self.overlap = overlap and self.world > 1
+        self.overlap = overlap and self._collectives
+        self._hooks_on = True
+        self._synced = False
         limit = max(int(bucket_mb * (1 << 20) / 4), 1)
         offsets = []
         off = 0
@@ -137,30 +168,66 @@ class DataParallel:
     def __call__(self, *a, **k):
         return self.module(*a, **k)
 
+    def attach_batch(self, batch) -> None:
+        """Mode B with a FakeQuantBatch: ds of every tensor is recomputed by the batch (two launches)."""
+        self._batch = batch
+        if self.mode == "B":
+            batch.defer_scale_grads = True
+
+    def no_sync(self):
+        """Context manager: backward passes inside accumulate into the bucket without exchanging anything."""
+        dp = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                dp._hooks_on = False
+
+            def __exit__(self_inner, *exc):
+                dp._hooks_on = True
+                return False
+        return _NoSync()
+
     def _make_hook(self, i):
         def hook(_param):
+            if not self._hooks_on:
+                return
             b = self._param_bucket[i]
+            if self._launched[b] or self._synced or self._remaining[b] <= 0:
+                raise RuntimeError("DataParallel: a gradient arrived for a bucket that was already exchanged -- a second "
+                                   "backward without dp.zero_grad().  For gradient accumulation run the earlier backward "
+                                   "passes under `with dp.no_sync():`")
             self._remaining[b] -= 1
-            if self._remaining[b] == 0 and not self._launched[b]:
+            if self._remaining[b] == 0:
                 self._launch(b)
         return hook
 
-    def _launch(self, b):
+    def _launch(self, b, async_op: bool = True):
         lo, hi = self._ranges[b]
         for i, p in enumerate(self.bucket.params):        # a grad re-allocated elsewhere goes back into the bucket first
             if self._param_bucket[i] == b and p.grad is not None and p.grad.data_ptr() != self.bucket.views[i].data_ptr():
                 self.bucket.views[i].copy_(p.grad)
                 p.grad = self.bucket.views[i]
         chunk = self.bucket.flat[lo:hi]
-        chunk.div_(self.world)
-        self._handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._avg is not None:
+            h = dist.all_reduce(chunk, op=self._avg, group=self.group, async_op=async_op)
+        else:
+            chunk.div_(self.world)
+            h = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            self._handles.append(h)
         self._launched[b] = True
 
-    def zero_grad(self):
-        self.bucket.zero_()
+    def begin_step(self):
+        """Host-side reset of the per-step state (what zero_grad() does besides zeroing the bucket); a captured step
+        replays the zeroing kernel itself and calls this before every replay."""
         self._remaining = list(self._pending_count)
         self._launched = [False] * len(self._ranges)
         self._handles = []
+        self._synced = False
+
+    def zero_grad(self):
+        self.bucket.zero_()
+        self.begin_step()
         if self.mode == "B":
             for s in self.scales:
                 s.grad = None
@@ -176,20 +243,34 @@ class DataParallel:
                         pairs.append((getattr(m, pname), nested))
         return pairs
 
-    def sync_gradients(self):
-        if self.world > 1:
-            self.bucket.gather_()
+    def exchange(self, capture_safe: bool = False):
+        """The all-reduce part of ``sync_gradients``.  ``capture_safe``: synchronous collectives on the current stream and
+        no host-side gathering (for recording the step into a hipGraph: gradients are the static bucket views then)."""
+        if self._collectives:
+            if not capture_safe:
+                self.bucket.gather_()
             for b in range(len(self._ranges)):
                 if not self._launched[b]:                  # parameters that got no gradient this step, or overlap=False
-                    self._launch(b)
+                    self._launch(b, async_op=not capture_safe)
             for h in self._handles:
                 h.wait()
             self._handles = []
-        if self.mode == "B":
-            fn = self._scale_grad_fn
-            if fn is None:
-                from . import ops
-                fn = ops.fq_scale_grad
-            for p, nested in self._nq_pairs():
-                # P.grad is now the global-batch dy (dP == dy, custom_layers.py:118)
-                nested.scale.grad = fn(p.data, nested.scale.data, p.grad, nested.penalty_threshold)
+        self._synced = True
+
+    def recompute_scale_grads(self):
+        """Mode B: ds from the all-reduced P.grad, which IS the global-batch dy (dP == dy, custom_layers.py:118)."""
+        if self.mode != "B":
+            return
+        if self._batch is not None and self._scale_grad_fn is None:
+            self._batch.scale_grads_from_param_grads()
+            return
+        fn = self._scale_grad_fn
+        if fn is None:
+            from . import ops
+            fn = ops.fq_scale_grad
+        for p, nested in self._nq_pairs():
+            nested.scale.grad = fn(p.data, nested.scale.data, p.grad, nested.penalty_threshold)
+
+    def sync_gradients(self):
+        self.exchange()
+        self.recompute_scale_grads()

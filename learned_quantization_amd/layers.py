@@ -133,6 +133,7 @@ class CustomQuantizedScaleLayer(nn.Module):
         self.scale: Optional[nn.Parameter] = None
         self.scale_name: Optional[str] = None
         self.built = False
+        self.defer_scale_grad = False          # set by DataParallel(mode="B"): ds is recomputed after the all-reduce
 
     def build(self, input_shape, device=None):
         shape = scale_shape(tuple(input_shape), self.orientation)  # raises ValueError like NQ-L:194-197
@@ -147,7 +148,8 @@ class CustomQuantizedScaleLayer(nn.Module):
             self.build(tuple(inputs.shape), device=inputs.device)
         if self.penalty_threshold is None:
             return ops.my_custom_gradient(inputs, self.scale)                        # CL-L:143-144
-        return ops.my_custom_gradient(inputs, self.scale, self.penalty_threshold)    # NQ-L:199-200
+        return ops.my_custom_gradient(inputs, self.scale, self.penalty_threshold,   # NQ-L:199-200
+                                      defer_scale_grad=self.defer_scale_grad)
 
     forward = call
 

@@ -36,10 +36,31 @@ def setup_logger(new_log_dir: str, logs: Sequence[str]) -> None:
             pass
 
 
+def softmax(logits: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """tf.keras.activations.softmax: the probabilities, with the logits attached as ``_keras_logits`` -- exactly what
+    Keras 2.11 does (keras/activations.py: ``output._keras_logits = x``) so that a later cross-entropy can be computed
+    from the logits.  The models of this package end in it, as the reference's models end in
+    ``Dense(..., activation='softmax')`` / ``tf.keras.activations.softmax`` (MNIST/nested_quantization_layer/
+    experiment.py:116,160; CIFAR-10/custom_loss_terms/experiment.py:269,428)."""
+    p = torch.softmax(logits, dim=dim)
+    p._keras_logits = logits
+    return p
+
+
 def sparse_categorical_crossentropy(y_true: torch.Tensor, y_pred: torch.Tensor) -> torch.Tensor:
-    """tf.keras.losses.sparse_categorical_crossentropy(y_true, y_pred) with probabilities in ``y_pred``:
-    -log(clip(p, 1e-7, 1 - 1e-7)[y]) per sample."""
+    """tf.keras.losses.sparse_categorical_crossentropy(y_true, y_pred) (from_logits=False), per sample.
+
+    Keras 2.11 (keras/backend.py ``sparse_categorical_crossentropy`` -> ``_get_logits``): when ``y_pred`` is the output
+    of a softmax activation it carries ``_keras_logits`` and the loss is computed FROM THE LOGITS
+    (``tf.nn.sparse_softmax_cross_entropy_with_logits`` = -log_softmax(logits)[y]), with no clipping -- the reference's
+    models all end in a softmax, so this is the branch its training runs (custom_loss_functions.py:52-54 passes the model
+    output straight through).  With the reference's raw 0..255 inputs the nets saturate at initialisation; from the logits
+    the gradient there is still softmax - onehot, where the clipped form below would give exactly zero.
+    Probabilities that do not come from ``softmax()`` take Keras' other branch: clip to [1e-7, 1 - 1e-7], then -log."""
     y = y_true.reshape(-1).long()
+    logits = getattr(y_pred, "_keras_logits", None)
+    if logits is not None:
+        return -torch.gather(torch.log_softmax(logits, dim=-1), 1, y.unsqueeze(1)).squeeze(1)
     p = torch.clamp(y_pred, _EPSILON, 1.0 - _EPSILON)
     return -torch.log(torch.gather(p, 1, y.unsqueeze(1)).squeeze(1))
 

@@ -196,18 +196,20 @@ class _NestedQuantFn(torch.autograd.Function):
     """custom_layers.py:49-120 -- forward K1, backward (dy, K2+K3, None)."""
 
     @staticmethod
-    def forward(ctx, parameter, scale, penalty_threshold):
+    def forward(ctx, parameter, scale, penalty_threshold, defer_scale_grad=False):
         ctx.save_for_backward(parameter, scale)
         ctx.penalty_threshold = float(penalty_threshold)
+        ctx.defer = bool(defer_scale_grad)
         return fq_forward(parameter, scale)
 
     @staticmethod
     def backward(ctx, dy):
         parameter, scale = ctx.saved_tensors
         ds = None
-        if ctx.needs_input_grad[1]:
+        # defer: exact data-parallel mode recomputes ds from the all-reduced dP after the exchange (ddp.py, mode B)
+        if ctx.needs_input_grad[1] and not ctx.defer:
             ds = fq_scale_grad(parameter, scale, dy, ctx.penalty_threshold)
-        return (dy if ctx.needs_input_grad[0] else None), ds, None      # :118  dP is dy itself (STE)
+        return (dy if ctx.needs_input_grad[0] else None), ds, None, None      # :118  dP is dy itself (STE)
 
 
 class _STEQuantFn(torch.autograd.Function):
@@ -225,14 +227,16 @@ class _STEQuantFn(torch.autograd.Function):
         return (dy if ctx.needs_input_grad[0] else None), ds
 
 
-def my_custom_gradient(parameter, scale, penalty_threshold=None):
+def my_custom_gradient(parameter, scale, penalty_threshold=None, *, defer_scale_grad=False):
     """The reference op.  With ``penalty_threshold`` -> nested-quantization variant
-    (custom_layers.py:49-120); without -> STE-only variant (CL custom_layers.py:49-64)."""
+    (custom_layers.py:49-120); without -> STE-only variant (CL custom_layers.py:49-64).
+    ``defer_scale_grad`` (not in the reference): backward returns dP only; the caller computes ds later from the
+    all-reduced dP (exact data-parallel mode, ddp.py)."""
     if penalty_threshold is None:
         return _STEQuantFn.apply(parameter, scale)
     if isinstance(penalty_threshold, torch.Tensor):
         penalty_threshold = float(penalty_threshold)      # tf.stop_gradient(penalty_threshold), :55
-    return _NestedQuantFn.apply(parameter, scale, penalty_threshold)
+    return _NestedQuantFn.apply(parameter, scale, penalty_threshold, defer_scale_grad)
 
 
 # --------------------------------------------------------------------------- penalty terms

@@ -44,25 +44,47 @@ def synthetic_batch(config: str, batch: int, device, generator: Optional[torch.G
 
 
 class Trainer:
+    """One training configuration: model, loss, optimizers, optional multi-tensor batch, hipGraph and data-parallel wrapper.
+
+    ``mode``: "nq" (nested quantization: ``value`` = penalty_threshold), "cl" (custom loss terms: ``value`` =
+    penalty_rate, ``loss`` names the term), "nqcl" (BASELINE.json configs[3], "nested quantization + custom_loss_terms
+    penalty": ``value`` = (penalty_threshold, penalty_rate); the scale gradient is the hand-written NQ gradient PLUS the
+    penalty's -- an extension without a reference call site, the reference never combines the two: CL-L:61-62).
+
+    A step is two phases: ``_backward_phase`` (zero the gradients, fake-quantise, forward, loss, backward, penalty
+    injection) and ``_update_phase`` (exact-mode scale gradients, both optimizers); between them the data-parallel
+    exchange.  ``graph=True`` records the phases into hipGraphs: one graph for the whole step on one GPU; with
+    ``world_size > 1`` either graph(backward) -> eager bucketed all-reduce -> graph(update) (default), or -- with
+    ``graph_collectives=True`` -- ONE graph that contains the RCCL all-reduce as well (RCCL kernels are capturable).
+    """
+
     def __init__(self, config="cifar", mode="nq", value=1e-11, orientation="channelwise", loss: Optional[str] = None,
-                 lr=1e-4, seed=42, device=None, ddp_mode="A", log_dir="logs", graph=False, batched=False):
+                 lr=1e-4, seed=42, device=None, ddp_mode="A", log_dir="logs", graph=False, batched=False,
+                 bucket_mb: float = 25.0, overlap: bool = True, graph_collectives: bool = False,
+                 force_collectives: bool = False):
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         torch.manual_seed(seed)
         L.reset_layer_names()
         self.config = config
+        self.mode = mode
         self.model = build_model(config, mode=mode, value=value, seed=seed, orientation=orientation, device=self.device)
         self.model.to(self.device)
         self.custom_layers = L.custom_layers_of(self.model)
         self.loss_obj = None
-        self.loss_kind, self.penalty_rate = loss, value
-        if mode == "cl":
+        self.loss_kind = loss
+        self.penalty_rate = value[1] if mode == "nqcl" else value
+        if mode in ("cl", "nqcl"):
             if loss not in LOSSES:
-                raise ValueError("mode 'cl' needs --loss maxbin|difference|inverse")
-            self.loss_obj = LOSSES[loss](self.custom_layers, value, log_dir)      # custom_loss_terms/experiment.py:436-455
+                raise ValueError(f"mode {mode!r} needs --loss maxbin|difference|inverse")
+            self.loss_obj = LOSSES[loss](self.custom_layers, self.penalty_rate, log_dir)   # custom_loss_terms/experiment.py:436-455
+        elif loss is not None:
+            raise ValueError("a loss term needs mode 'cl' or 'nqcl'")
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.dp = DataParallel(self.model, mode=ddp_mode) if self.world > 1 else None
-        if graph and self.world > 1:
-            raise ValueError("graph capture of the whole step is single-GPU only (the all-reduce stays eager)")
+        use_dp = self.world > 1 or (force_collectives and dist.is_initialized())
+        # graphed steps exchange after backward (hooks cannot launch collectives from inside a capture that is replayed
+        # without them): overlap is a property of the eager step
+        self.dp = DataParallel(self.model, mode=ddp_mode, bucket_mb=bucket_mb, overlap=overlap and not graph,
+                               force_collectives=force_collectives) if use_dp else None
         # Keras 2.11 Adam (lr 1e-4, eps 1e-7 outside the bias correction) for every ordinary parameter in one launch
         self.opt = KerasAdam(non_scale_parameters(self.model), lr=lr, eps=1e-7, capturable=graph)
         self.batch = None
@@ -73,10 +95,14 @@ class Trainer:
                 self.dp.zero_grad()          # makes scale.grad the bucket views the batch will write into
             self.batch = FakeQuantBatch(self.model, lr=lr)
             self.scale_opt = BatchedScaleAdam(self.batch, capturable=graph)
+            if self.dp is not None:
+                self.dp.attach_batch(self.batch)
         else:
             self.scale_opt = ScaleAdam(scale_parameters(self.model), lr=lr, capturable=graph)
         self.regularized = [l for l in self.custom_layers if l.regularizer is not None]
         self.graph = None
+        self.graph_update = None
+        self.graph_collectives = graph_collectives
         self._want_graph = graph
 
     def loss(self, y, p):
@@ -89,7 +115,8 @@ class Trainer:
             total = total + layer.regularization_loss()
         return total
 
-    def step(self, x, y):
+    # ---------------------------------------------------------------- the two phases of a step
+    def _backward_phase(self, x, y):
         self.model.train()
         if self.dp is not None:
             self.dp.zero_grad()
@@ -102,18 +129,36 @@ class Trainer:
         loss.backward()
         if self.batch is not None and self.loss_obj is not None:
             # batched custom-loss-terms mode: the task loss went through autograd, the penalty gradients are injected
-            # by the batch kernels (identical on every rank, so adding them before the all-reduce changes nothing)
-            self.batch.inject_penalty_grads(self.loss_kind, self.penalty_rate)
-        if self.dp is not None:
-            self.dp.sync_gradients()
-        self.opt.step()
-        self.scale_opt.step()
+            # by the batch kernels (identical on every rank, so adding them before the all-reduce changes nothing);
+            # "nqcl": the penalty's ds is ADDED to the nested-quantization ds the batch has just written
+            self.batch.inject_penalty_grads(self.loss_kind, self.penalty_rate, accumulate_ds=(self.mode == "nqcl"))
         return loss
 
+    def _update_phase(self):
+        if self.dp is not None:
+            self.dp.recompute_scale_grads()          # mode B only
+        self.opt.step()
+        self.scale_opt.step()
+
+    def step(self, x, y):
+        loss = self._backward_phase(x, y)
+        if self.dp is not None:
+            self.dp.exchange()
+        self._update_phase()
+        return loss
+
+    def _capture(self, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        return g, out
+
     def step_graphed(self, x, y):
-        """The whole training step (forward, loss, backward, both optimizers) as ONE hipGraph launch.
-        The step is launch-bound at these model sizes (hundreds of small kernels); capture removes the
-        host from the loop.  First call: 3 eager warm-up steps on a side stream, then capture."""
+        """The training step as hipGraph launches.  These steps are launch-bound (hundreds of small kernels); capture
+        removes the host from the loop.  First call: 3 eager warm-up steps on a side stream, then capture.
+        One GPU: ONE graph (forward, loss, backward, both optimizers).  Data parallel: graph(backward phase) -> eager
+        bucketed RCCL all-reduce -> graph(update phase); or, with ``graph_collectives``, one graph including the
+        all-reduce (synchronous collectives on the capturing stream)."""
         if self.graph is None:
             self._x = torch.empty_like(x)
             self._y = torch.empty_like(y)
@@ -126,14 +171,29 @@ class Trainer:
                     self.step(self._x, self._y)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
-            self.graph = torch.cuda.CUDAGraph()
-            self.opt.zero_grad(set_to_none=True)
-            self.scale_opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(self.graph):
-                self._loss = self.step(self._x, self._y)
+            if self.dp is None:
+                self.opt.zero_grad(set_to_none=True)
+                self.scale_opt.zero_grad(set_to_none=True)
+                self.graph, self._loss = self._capture(lambda: self.step(self._x, self._y))
+            elif self.graph_collectives:
+                def whole():
+                    loss = self._backward_phase(self._x, self._y)
+                    self.dp.exchange(capture_safe=True)
+                    self._update_phase()
+                    return loss
+                self.graph, self._loss = self._capture(whole)
+            else:
+                self.graph, self._loss = self._capture(lambda: self._backward_phase(self._x, self._y))
+                self.dp.exchange()
+                self.graph_update, _ = self._capture(self._update_phase)
         self._x.copy_(x)
         self._y.copy_(y)
+        if self.dp is not None:
+            self.dp.begin_step()
         self.graph.replay()
+        if self.graph_update is not None:
+            self.dp.exchange()
+            self.graph_update.replay()
         return self._loss
 
     @torch.no_grad()
@@ -146,8 +206,11 @@ class Trainer:
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=list(INPUT_SHAPES), default="cifar")
-    ap.add_argument("--mode", choices=["nq", "cl"], default="nq")
-    ap.add_argument("--value", type=float, default=1e-11, help="penalty_threshold (nq) or penalty_rate (cl)")
+    ap.add_argument("--mode", choices=["nq", "cl", "nqcl"], default="nq")
+    ap.add_argument("--value", type=float, default=1e-11, help="penalty_threshold (nq, nqcl) or penalty_rate (cl)")
+    ap.add_argument("--rate", type=float, default=1e-7, help="penalty_rate of the loss term in mode nqcl")
+    ap.add_argument("--value-coarse", type=float, default=None,
+                    help="resnet50 only: threshold of the 3x3 kernels ('mixed' quantisation intensity); --value is the rest")
     ap.add_argument("--orientation", default="channelwise")
     ap.add_argument("--loss", choices=list(LOSSES), default=None)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
@@ -156,7 +219,10 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--ddp-mode", choices=["A", "B"], default="A")
     ap.add_argument("--export-dir", default=None, help="write the reference's integer export here at the end")
-    ap.add_argument("--graph", action="store_true", help="capture the whole step in a hipGraph (single GPU)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs (N > 1: graph / all-reduce / graph)")
+    ap.add_argument("--graph-collectives", action="store_true", help="N > 1: capture the RCCL all-reduce inside ONE graph")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one rank (RCCL rehearsal on one GPU)")
+    ap.add_argument("--bucket-mb", type=float, default=25.0)
     ap.add_argument("--backend", default="nccl", help="nccl = RCCL over xGMI (default); gloo + --share-gpu rehearses N>1 on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--batched", action="store_true", help="multi-tensor launches for all fake-quant ops of a step (lq_batch_*)")
@@ -165,6 +231,8 @@ def main(argv=None):
                          "+17 %% on the ResNet-18-like config, -17 %% on the small CIFAR CNN")
     args = ap.parse_args(argv)
 
+    # read by the HSA runtime when it initialises (the first torch.cuda call below): the host driver only supports dmabuf IPC
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -175,16 +243,25 @@ def main(argv=None):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if world == 1:
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
-    rank = dist.get_rank() if world > 1 else 0
+    rank = dist.get_rank() if use_dist else 0
 
-    tr = Trainer(args.config, args.mode, args.value, args.orientation, args.loss, seed=args.seed, device=dev,
-                 ddp_mode=args.ddp_mode, graph=args.graph, batched=args.batched)
+    value = args.value
+    if args.mode == "nqcl":
+        value = (args.value, args.rate)
+    elif args.config == "resnet50" and args.value_coarse is not None:
+        value = (args.value_coarse, args.value)
+    tr = Trainer(args.config, args.mode, value, args.orientation, args.loss, seed=args.seed, device=dev,
+                 ddp_mode=args.ddp_mode, graph=args.graph, batched=args.batched, bucket_mb=args.bucket_mb,
+                 graph_collectives=args.graph_collectives, force_collectives=args.force_dist)
     do_step = tr.step_graphed if args.graph else tr.step
     g = torch.Generator(device=dev).manual_seed(args.seed + rank)
     batches = [synthetic_batch(args.config, args.batch, dev, g) for _ in range(4)]
@@ -193,16 +270,16 @@ def main(argv=None):
     for i in range(args.warmup):
         do_step(*batches[i % 4])
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = do_step(*batches[i % 4])
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -213,12 +290,13 @@ def main(argv=None):
             "value": world * args.batch * args.steps / dt, "unit": "images/s", "n_gpus": world,
             "ms_per_step": dt / args.steps * 1e3, "per_gpu_batch": args.batch, "orientation": args.orientation,
             "loss_term": args.loss, "quantized_elements": n_q, "final_loss": float(loss), "ddp_mode": args.ddp_mode,
-            "hipgraph": bool(args.graph), "batched": bool(args.batched),
+            "hipgraph": bool(args.graph), "graph_collectives": bool(args.graph_collectives), "batched": bool(args.batched),
+            "backend": (args.backend if use_dist else None),
             "channels_last": bool(args.channels_last)}))
         if args.export_dir:
             from .export import save_compress_parameters
             print(json.dumps(save_compress_parameters(tr.model, args.export_dir)))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

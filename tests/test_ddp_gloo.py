@@ -130,6 +130,59 @@ def test_data_parallel_two_ranks(tmp_path, mode):
         np.testing.assert_allclose(r0["nested_q_w_layer.scale"].numpy(), (locals_[0] + locals_[1]) / 2, rtol=1e-5)
 
 
+def _accum_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from learned_quantization_amd.ddp import DataParallel
+    model = _FakeLayer(2e-2)
+    dp = DataParallel(model, mode="A", scale_grad_fn=_oracle_scale_grad, bucket_mb=1e-5)
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 12, generator=g), torch.randn(8, 5, generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    res = {}
+    # (1) a second backward into buckets that were already exchanged must raise, not silently diverge
+    dp.zero_grad()
+    ((dp(xs) - ys) ** 2).sum().backward()
+    dp.sync_gradients()
+    try:
+        ((dp(xs) - ys) ** 2).sum().backward()
+        res["second_backward"] = "no error"
+    except RuntimeError as e:
+        res["second_backward"] = str(e)
+    # (2) gradient accumulation: earlier passes under no_sync(), the last one exchanges the accumulated bucket
+    dp.zero_grad()
+    with dp.no_sync():
+        ((dp(xs[:2]) - ys[:2]) ** 2).sum().backward()
+    ((dp(xs[2:]) - ys[2:]) ** 2).sum().backward()
+    dp.sync_gradients()
+    res["W_accum"] = model.W.grad.clone()
+    torch.save(res, os.path.join(out_dir, f"acc{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_and_double_backward_guard(tmp_path):
+    port = _free_port()
+    mp.spawn(_accum_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "acc0.pt"), torch.load(tmp_path / "acc1.pt")
+    assert "no_sync" in r0["second_backward"] and "no_sync" in r1["second_backward"]
+    assert torch.equal(r0["W_accum"], r1["W_accum"])
+    # reference: mean over ranks of the per-rank summed-loss gradients
+    sys.path.insert(0, ROOT)
+    g = torch.Generator().manual_seed(5)
+    X, Y = torch.randn(8, 12, generator=g), torch.randn(8, 5, generator=g)
+    grads = []
+    for r in range(2):
+        m = _FakeLayer(2e-2)
+        xs, ys = X[r * 4:(r + 1) * 4], Y[r * 4:(r + 1) * 4]
+        ((m(xs[:2]) - ys[:2]) ** 2).sum().backward()
+        ((m(xs[2:]) - ys[2:]) ** 2).sum().backward()
+        grads.append(m.W.grad)
+    np.testing.assert_allclose(r0["W_accum"].numpy(), ((grads[0] + grads[1]) / 2).numpy(), rtol=1e-5, atol=1e-7)
+
+
 def test_grad_bucket_single_process():
     sys.path.insert(0, ROOT)
     from learned_quantization_amd.ddp import GradBucket

@@ -30,7 +30,8 @@ def _model(dev, config, orient, mode="nq", value=1e-3, seed=3):
 
 @pytest.mark.parametrize("config,orient", [("mnist", "rowwise"), ("mnist", "columnwise"), ("cifar", "channelwise"),
                                            ("cifar", "rowwise"), ("cifar", "columnwise"), ("cifar", "scalar"),
-                                           ("imagenette", "channelwise")])
+                                           ("imagenette", "channelwise"), ("resnet50", "channelwise"),
+                                           ("resnet50", "columnwise")])
 def test_batch_equals_single_tensor_ops_bitwise(dev, config, orient):
     import learned_quantization_amd as lq
     m = _model(dev, config, orient)

@@ -47,7 +47,7 @@ def _worker(rank, world, port, mode, batched, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,batched", [("A", False), ("B", False), ("A", True)])
+@pytest.mark.parametrize("mode,batched", [("A", False), ("B", False), ("A", True), ("B", True)])
 def test_two_rank_training_on_one_gpu(tmp_path, mode, batched):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, mode, batched, str(tmp_path)), nprocs=2, join=True)
@@ -66,3 +66,41 @@ def test_two_rank_training_on_one_gpu(tmp_path, mode, batched):
             tr.step(x, y)
         for n, p in tr.model.named_parameters():
             np.testing.assert_allclose(r0[n].numpy(), p.detach().cpu().numpy(), rtol=2e-5, atol=1e-9, err_msg=n)
+
+
+def _run_script(args, timeout=600):
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    return res.stdout
+
+
+def test_one_rank_rccl_rehearsal():
+    """backend "nccl" (= RCCL) with `device_id=` init on the one GPU of the box: DataParallel's async hook path, modes A/B,
+    the batch, and both graphed forms of the step -- all must reproduce the plain trainer (ReduceOp.AVG over one rank is
+    the identity).  tests/tools/ddp_rehearsal.py runs in its own process so that the process group exists before any GPU call."""
+    import json
+    out = _run_script([os.path.join(ROOT, "tests", "tools", "ddp_rehearsal.py"), str(_free_port())])
+    line = [l for l in out.splitlines() if l.startswith("REHEARSAL ")][-1]
+    res = json.loads(line[len("REHEARSAL "):])
+    for name in ("A_hooks_tiny_buckets", "A_no_overlap", "A_batched", "B", "B_batched"):
+        assert res[name]["max_param_diff"] == 0.0, (name, res[name])
+        assert all(np.isfinite(l) for l in res[name]["losses"])
+    assert res["A_hooks_tiny_buckets"]["buckets"] > 2
+    for name in ("graph_split_A_batched", "graph_split_B_batched", "graph_split_A"):
+        assert "error" not in res[name], (name, res[name])
+        assert res[name]["graphs"] == 2 and res[name]["max_rel_param_diff_vs_eager"] < 1e-5, (name, res[name])
+        np.testing.assert_allclose(res[name]["losses"], res[name]["eager_losses"], rtol=1e-5)
+    # ONE graph with the RCCL all-reduce captured inside: must work on this stack, or the failure is on record
+    for name in ("graph_collectives_A_batched", "graph_collectives_B_batched"):
+        assert "error" not in res[name], (name, res[name])
+        assert res[name]["graphs"] == 1 and res[name]["max_rel_param_diff_vs_eager"] < 1e-5, (name, res[name])
+
+
+def test_bench_force_dist_one_rank_rccl():
+    """bench.py with torch.distributed initialised on RCCL (one rank): the scale-gradient all-reduce (ReduceOp.AVG) runs every step."""
+    import json
+    out = _run_script([os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extras"])
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1e5 and line["roofline"]["frac"] > 0.5

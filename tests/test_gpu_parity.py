@@ -104,6 +104,41 @@ def test_random_parity_all_modes(shape, orient, dev):
         _check_case(P, s, dy, lam, dev, f"{shape} {orient} lam={lam}")
 
 
+# streaming-size (>= 4 M elements) forms of csrc/lq_stream2.hpp: flat K1, pipelined column tile, pipelined periodic
+# columns, tiny-row passes -- every template branch (group arithmetic, team width, ragged edges)
+STREAM2_SHAPES = [
+    ((20000, 256), "columnwise"),      # column tile, one column block, contiguous tiles
+    ((2100, 2100), "columnwise"),      # column tile, 9 column blocks, the last one partial (2100 = 8*256 + 52)
+    ((4099, 1028), "columnwise"),      # rows not a multiple of the row block
+    ((600, 1024, 8), "columnwise"),    # inner = 8: one group per float4 (flat K1 group mode 0)
+    ((1100, 1024, 4), "columnwise"),   # inner = 4
+    ((700, 1000, 6), "columnwise"),    # inner = 6: float4s straddle groups (C = 6000)
+    ((140000, 32), "rowwise"),         # tiny rows, 8 lanes per row, outer == 1: direct emit
+    ((3, 50000, 32), "columnwise"),    # tiny rows with outer > 1: group-major partials + finalize
+    ((200000, 24), "rowwise"),         # 6 of 8 lanes active
+    ((300000, 16), "rowwise"),         # 4 lanes per row
+    ((600000, 8), "rowwise"),          # 2 lanes per row
+    ((100000, 48), "rowwise"),         # 12 of 16 lanes
+    ((70001, 64), "rowwise"),          # 16 lanes per row, ragged last wave
+    ((9000, 512), "rowwise"),          # rows of 512: round-1 row-small traversal, flat forward
+    ((5, 1000000), "columnwise"),      # G = 1 M groups of one element each (inner = 1, outer = 5): column tile with C = 1 M
+]
+
+
+@pytest.mark.parametrize("shape,orient", STREAM2_SHAPES)
+def test_streaming_forms_parity(shape, orient, dev):
+    rng = np.random.default_rng(stable_seed(shape, orient))
+    for lam in (1e-10, 3e-2):
+        P = rng.normal(0, 0.05, size=shape).astype(np.float32)
+        dy = (rng.normal(0, 1, size=shape) * 10.0 ** rng.uniform(-9, -2, size=shape)).astype(np.float32)
+        s = rng.uniform(1e-3, 3e-2, size=O.scale_shape(shape, orient)).astype(np.float32)
+        _check_case(P, s, dy, lam, dev, f"{shape} {orient} lam={lam}")
+    # integer view through the same traversals
+    import learned_quantization_amd as lq
+    q = lq.quantized_integers(_t(P, dev), _t(s, dev), torch.int32).cpu().numpy()
+    np.testing.assert_array_equal(q, O.quantized_integers(P, s).astype(np.int32))
+
+
 RESNET18_KERNELS = [(7, 7, 3, 64), (3, 3, 64, 64), (3, 3, 64, 128), (3, 3, 128, 128), (1, 1, 64, 128), (3, 3, 128, 256),
                     (3, 3, 256, 256), (1, 1, 128, 256), (3, 3, 256, 512), (3, 3, 512, 512), (1, 1, 256, 512)]
 
@@ -120,6 +155,43 @@ def test_resnet18_kernel_shapes_full_size(orient, dev):
         for s, lam in ((rng.uniform(1e-3, 3e-2, size=sshape).astype(np.float32), 3e-2),
                        (np.full(sshape, O.SCALE_MIN, np.float32), 1e-11)):
             _check_case(P, s, dy, lam, dev, f"{shape} {orient} lam={lam}")
+
+
+# BASELINE.json configs[4] (ResNet-50, "mixed 4/8-bit"): every distinct quantised tensor of the bottleneck topology
+# (learned_quantization_amd/models.py::ResNet50Like -- an extension, the reference has no ResNet-50; the op is shape-generic)
+RESNET50_TENSORS = [(7, 7, 3, 64), (1, 1, 64, 64), (1, 1, 64, 256), (1, 1, 256, 64), (3, 3, 64, 64), (1, 1, 256, 128),
+                    (3, 3, 128, 128), (1, 1, 128, 512), (1, 1, 256, 512), (1, 1, 512, 128), (1, 1, 512, 256), (3, 3, 256, 256),
+                    (1, 1, 256, 1024), (1, 1, 512, 1024), (1, 1, 1024, 256), (1, 1, 1024, 512), (3, 3, 512, 512),
+                    (1, 1, 512, 2048), (1, 1, 1024, 2048), (1, 1, 2048, 512), (2048, 10), (2048, 1000), (2048,), (1000,)]
+
+
+def test_resnet50_tensor_list_matches_the_model():
+    import learned_quantization_amd as lq
+    from learned_quantization_amd.models import ResNet50Like
+    lq.reset_layer_names()
+    m = ResNet50Like()
+    shapes = {tuple(p.shape) for l in lq.custom_layers_of(m) for p in l._regularized()}
+    assert {sh for sh in shapes if len(sh) > 1} <= set(RESNET50_TENSORS)
+    assert len(lq.custom_layers_of(m)) == 54 and sum(len(l._regularized()) for l in lq.custom_layers_of(m)) == 108
+
+
+@pytest.mark.parametrize("orient", ["rowwise", "columnwise", "channelwise", "scalar"])
+def test_resnet50_kernel_shapes_full_size(orient, dev):
+    """BASELINE configs[4] at full size: every bottleneck shape (1x1x64x256 ... 1x1x1024x2048, the 3x3 mids, the 7x7 stem, the
+    2048x10 / 2048x1000 classifiers and the biases), each orientation, "mixed" thresholds per layer: the coarse one for 3x3
+    kernels, the fine one elsewhere, once with trained-like scales and once at the reference's initial scale."""
+    rng = np.random.default_rng(5050)
+    for shape in RESNET50_TENSORS:
+        o = orient if len(shape) > 1 else "scalar"                 # biases always have a scalar scale (NQ-L:225-227)
+        if o == "channelwise" and len(shape) < 3:
+            o = "rowwise"
+        P = rng.normal(0, 0.05, size=shape).astype(np.float32)
+        dy = (rng.normal(0, 1, size=shape) * 10.0 ** rng.uniform(-9, -2, size=shape)).astype(np.float32)
+        sshape = O.scale_shape(shape, o)
+        lam_trained, lam_init = (3e-2, 1e-10) if (len(shape) == 4 and shape[0] == 3) else (1e-6, 1e-11)
+        for s, lam in ((rng.uniform(1e-3, 3e-2, size=sshape).astype(np.float32), lam_trained),
+                       (np.full(sshape, O.SCALE_MIN, np.float32), lam_init)):
+            _check_case(P, s, dy, lam, dev, f"{shape} {o} lam={lam}")
 
 
 def test_init_scale_large_integers(dev):

@@ -172,6 +172,65 @@ def test_sparse_categorical_crossentropy_matches_oracle():
     assert got[0] == pytest.approx(-np.log(1e-7), rel=1e-5)
 
 
+def test_crossentropy_of_a_softmax_output_is_computed_from_the_logits():
+    """Keras 2.11 (keras/backend.py sparse_categorical_crossentropy -> _get_logits): the output of a softmax activation carries
+    its logits and the loss is -log_softmax(logits)[y], unclipped.  Saturated logits (the reference feeds raw 0..255 pixels;
+    its nets saturate at initialisation) must still back-propagate softmax - onehot, where clip-then-log gives exactly 0."""
+    from learned_quantization_amd.losses import softmax
+    logits = torch.tensor([[60.0, 0.0, -40.0, 5.0], [0.0, 90.0, 1.0, 2.0], [0.3, 0.1, -0.2, 0.0]], requires_grad=True)
+    y = torch.tensor([1, 0, 2])                                     # samples 0 and 1: p[y] < 1e-7, i.e. clipped in the other branch
+    p = softmax(logits, dim=1)
+    assert p._keras_logits is logits
+    loss = lq.sparse_categorical_crossentropy(y, p)
+    want = -torch.log_softmax(logits.detach().double(), dim=1)[torch.arange(3), y]
+    np.testing.assert_allclose(loss.detach().numpy(), want.numpy(), rtol=1e-6)
+    assert loss[0] > 16.2 and loss[1] > 16.2                         # beyond -log(1e-7) = 16.1: nothing was clipped
+    loss.sum().backward()
+    onehot = torch.zeros(3, 4)
+    onehot[torch.arange(3), y] = 1.0
+    np.testing.assert_allclose(logits.grad.numpy(), (torch.softmax(logits.detach(), 1) - onehot).numpy(), rtol=1e-5, atol=1e-7)
+    assert float(logits.grad[0].abs().max()) > 0.99                 # saturated sample: gradient alive
+    # the clip-and-log branch for probabilities that do not come from softmax(): zero gradient once clipped (Keras does the same)
+    lg2 = logits.detach().clone().requires_grad_(True)
+    p2 = torch.softmax(lg2, dim=1)
+    lq.sparse_categorical_crossentropy(y, p2).sum().backward()
+    assert float(lg2.grad[0].abs().max()) == 0.0 and float(lg2.grad[2].abs().max()) > 0.0
+    # every model of the package ends in losses.softmax
+    import inspect
+    from learned_quantization_amd import models
+    for cls in (models.MNISTDense, models.CIFARCNN, models.ResNet18Like, models.ResNet50Like):
+        assert "return softmax(" in inspect.getsource(cls.forward)
+
+
+def test_library_is_not_handed_out_before_the_device_selftest_passed(monkeypatch):
+    """_hip.load(): `_lib` is published only after the self-test ran and passed; a failure is remembered and re-raised by
+    every later load(); a load during stream capture (or without a visible GPU) defers the test instead of cancelling it."""
+    from learned_quantization_amd import _hip
+    saved = (_hip._lib, _hip._pending, _hip._selftest_error)
+    try:
+        _hip._lib, _hip._pending, _hip._selftest_error = None, None, None
+        calls = []
+        monkeypatch.setattr(_hip, "_device_selftest", lambda lib: calls.append(1) or False)      # deferred
+        a = _hip.load()
+        assert _hip._lib is None and _hip._pending is a
+        assert _hip.load() is a and len(calls) == 2                                              # retried, same handle
+
+        def failing(lib):
+            _hip._selftest_error = "device self-test failed (simulated)"
+            raise RuntimeError(_hip._selftest_error)
+        monkeypatch.setattr(_hip, "_device_selftest", failing)
+        with pytest.raises(RuntimeError, match="self-test failed"):
+            _hip.load()
+        monkeypatch.setattr(_hip, "_device_selftest", lambda lib: True)
+        with pytest.raises(RuntimeError, match="self-test failed"):                              # remembered
+            _hip.load()
+        assert _hip._lib is None
+        _hip._selftest_error = None
+        assert _hip.load() is a and _hip._lib is a                                               # passes -> published
+    finally:
+        _hip._lib, _hip._pending, _hip._selftest_error = saved
+
+
 def test_missing_extension_fails_loudly():
     """No silent fallback: if liblq_hip.so is absent every op raises (checked in a fresh interpreter)."""
     import subprocess

@@ -39,12 +39,14 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
-    for config, lam in (("mnist", 1e-10), ("cifar", 1e-11), ("imagenette", 1e-11)):
+    for config, lam in (("mnist", 1e-10), ("cifar", 1e-11), ("imagenette", 1e-11), ("resnet50", 1e-11)):
         for orient in (("rowwise", "columnwise", "scalar") if config == "mnist" else ("rowwise", "columnwise", "channelwise", "scalar")):
             if args.only and args.only != f"{config}:{orient}":
                 continue
             lq.reset_layer_names()
-            model = lq.build_model(config, mode="nq", value=lam, seed=42, orientation=orient, device=dev)
+            # resnet50 (BASELINE configs[4], 108 tensors, 23.5 M el): "mixed" thresholds, 1e-10 on the 3x3 kernels, 1e-11 elsewhere
+            model = lq.build_model(config, mode="nq", value=(1e-10, lam) if config == "resnet50" else lam, seed=42,
+                                   orientation=orient, device=dev)
             batch = lq.FakeQuantBatch(model)
             opt = lq.BatchedScaleAdam(batch)
             g = torch.Generator(device=dev).manual_seed(42)
@@ -62,7 +64,7 @@ def main():
             def per_tensor_step():
                 for e, d in zip(batch.entries, dys):
                     lq.fq_forward(e.param.data, e.nested.scale.data)
-                    e.nested.scale.grad = lq.fq_scale_grad(e.param.data, e.nested.scale.data, d, lam)
+                    e.nested.scale.grad = lq.fq_scale_grad(e.param.data, e.nested.scale.data, d, e.nested.penalty_threshold)
                 single_opt.step()
 
             # raw C-ABI cost without autograd/python per-tensor glue
