@@ -21,9 +21,9 @@ each step -- the only exchange this path has.
 Prints ONE JSON line on rank 0 (contract in the task statement) including
   "roofline":     K1, K2 and K4 each timed live with HIP events on the launch stream in a dedicated region right after
                   the timed loop: a FIXED number of isolated launches per kernel (independent of --steps), the
-                  cost of an empty event pair subtracted; the traversal kernel of the two-launch calls is
-                  bracketed alone through lq_profile_mark.  "kernel" names the one with the largest total per
-                  step.  "traffic" = HBM bytes per launch from the committed rocprofv3 PMC passes
+                  events stamped by the kernel dispatch itself (lq_profile_events -> hipExtLaunchKernelGGL), so
+                  the interval is the kernel's own duration as rocprofv3 reports it.  "kernel" names the one with
+                  the largest total per step.  "traffic" = HBM bytes per launch from the committed rocprofv3 PMC passes
                   (profiles/traffic.json), reported only while the kernel sources still hash to what was profiled
   "cpu_baseline": the op-for-op torch-CPU restatement of the reference path (oracle/lq_oracle_torch.py)
                   timed on this box's host cores on a bounded sample -- a baseline, not a target.
@@ -278,52 +278,46 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline leg: every kernel of the path, ROOF_SAMPLES isolated launches each, HIP events on the launch stream.
-    # Independent of --steps.  elapsed(ev0, ev1) around one launch = kernel duration + what an event pair costs by itself
-    # (measured on empty pairs and subtracted).  The two-launch calls record a third event between traversal and
-    # finalize (lq_profile_mark), so K2 / K4 / K3 are each bracketed alone.
+    # ---- roofline leg: every kernel of the path, ROOF_SAMPLES isolated launches each, independent of --steps.  The kernels
+    # are launched through the ABI with lq_profile_events(start, stop): hipExtLaunchKernelGGL stamps the two events with the
+    # kernel's own begin and end (the duration rocprofv3 reports) -- no event-record cost inside the interval, and the
+    # finalize launch of the two-launch calls stays outside it.  The call-level time (events recorded around the call on
+    # the launch stream, finalize included) is reported next to it.
     ROOF_SAMPLES = 24
     Ev = lambda: torch.cuda.Event(enable_timing=True)          # noqa: E731
-    mark = Ev()
-    mark.record(stream)                                        # torch creates the hipEvent_t lazily, at the first record
-    torch.cuda.synchronize(dev)
 
-    def pairs(launch, with_mark):
-        out = []
+    def live(ev):
+        ev.record(stream)                                      # torch creates the hipEvent_t lazily, at the first record
+        return ev
+
+    def sample(launch):
+        kern, call = [], []
         for j in range(ROOF_SAMPLES + 4):
-            e0, e1, em = Ev(), Ev(), (Ev() if with_mark else None)
-            if with_mark:
-                em.record(stream)
-                lib.lq_profile_mark(em.cuda_event)
-            e0.record(stream)
+            ks, ke, c0, c1 = live(Ev()), live(Ev()), Ev(), Ev()
+            lib.lq_profile_events(ks.cuda_event, ke.cuda_event)
+            c0.record(stream)
             rc = launch(j % nsets)
-            e1.record(stream)
-            if with_mark:
-                lib.lq_profile_mark(None)
+            c1.record(stream)
+            lib.lq_profile_events(None, None)
             if rc:
                 _hip.check(rc, "roofline leg")
-            out.append((e0, em, e1))
+            kern.append((ks, ke))
+            call.append((c0, c1))
         torch.cuda.synchronize(dev)
-        return out[4:]                                          # the first four warm the path
+        mean_us = lambda prs: sum(a.elapsed_time(b) for a, b in prs[4:]) / len(prs[4:]) * 1e3      # noqa: E731  (first four warm the path)
+        return mean_us(kern), mean_us(call)
 
-    def mean_us(vals):
-        return sum(vals) / len(vals) * 1e3
-
-    empty = mean_us([a.elapsed_time(c) for a, _, c in pairs(lambda k: 0, False)])
-    pk1 = pairs(lambda k: fwd(px[k], ps, pout[k], None, 0, outer, G, inner, sp), False)
-    pk2 = pairs(lambda k: bwd(px[k], ps, pdy[k], lam, pds, None, pws, ws_bytes, outer, G, inner, sp), True)
-    pk4 = pairs(lambda k: fused(px[k], ps, pdy[k], lam, pout[k], pds, pws, ws_bytes, outer, G, inner, sp), True)
-    t_k1 = mean_us([a.elapsed_time(c) for a, _, c in pk1]) - empty
-    t_k2 = mean_us([a.elapsed_time(m) for a, m, _ in pk2]) - empty
-    t_k3 = mean_us([m.elapsed_time(c) for _, m, c in pk2]) - empty
-    t_k4 = mean_us([a.elapsed_time(m) for a, m, _ in pk4]) - empty
+    t_k1, c_k1 = sample(lambda k: fwd(px[k], ps, pout[k], None, 0, outer, G, inner, sp))
+    t_k2, c_k2 = sample(lambda k: bwd(px[k], ps, pdy[k], lam, pds, None, pws, ws_bytes, outer, G, inner, sp))
+    t_k4, c_k4 = sample(lambda k: fused(px[k], ps, pdy[k], lam, pout[k], pds, pws, ws_bytes, outer, G, inner, sp))
+    call_us = {"K1": c_k1, "K2": c_k2, "K4": c_k4}
     kernels = {}
     for name, t_us, nbytes in (("K1 k_row_stream<OP_FWD> (lq_fq_forward)", t_k1, BYTES_FWD),
                                ("K2 k_row_stream<OP_BWD> (lq_fq_scale_grad, traversal)", t_k2, BYTES_BWD),
                                ("K4 k_row_stream<OP_FUSED> (lq_fq_fwd_bwd_fused, traversal)", t_k4, BYTES_FUSED)):
         gbs = nbytes / (t_us * 1e-6) / 1e9
-        kernels[name] = {"avg_launch_us": t_us, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
-    kernels["K3 k_finalize_block (second launch of lq_fq_scale_grad)"] = {"avg_launch_us": t_k3}
+        kernels[name] = {"avg_launch_us": t_us, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS,
+                         "call_us_events_around_the_abi_call": call_us[name[:2]]}
     if args.variant == "split":
         # the step runs K1, K2, K3: the dominant kernel is the one with the largest total per step
         kname = max(list(kernels)[:2], key=lambda k: kernels[k]["avg_launch_us"])
@@ -333,9 +327,10 @@ def main():
         step_bytes = BYTES_FUSED
     kt = kernels[kname]["avg_launch_us"] * 1e-6
     kbytes = kernels[kname]["algorithmic_bytes_per_launch"]
-    extra = {"kernels": kernels, "event_samples_per_kernel": ROOF_SAMPLES, "empty_event_pair_us": empty,
-             "method": "mean over isolated launches of elapsed(event before, event after) minus the empty-pair cost; "
-                       "region placed after the timed loop, independent of --steps"}
+    extra = {"kernels": kernels, "event_samples_per_kernel": ROOF_SAMPLES,
+             "method": "mean over isolated launches of hipEventElapsedTime(start, stop) with the events stamped by the kernel "
+                       "dispatch itself (hipExtLaunchKernelGGL through lq_profile_events); region placed after the timed loop, "
+                       "independent of --steps"}
 
     # ---- informational extras (not part of `value`): other variants of the same step, 100 steps each, no events
     extras = {}

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LQ_ABI_VERSION 1
+#define LQ_ABI_VERSION 2
 
 typedef enum lq_status {
     LQ_OK = 0,
@@ -177,6 +177,10 @@ typedef struct lq_tensor_desc {
     int64_t outer, G, inner;
     float lambda;        /* penalty_threshold, or NaN for STE-only               */
     float min_value;     /* MinValueConstraint bound used by lq_batch_scale_adam */
+    /* conv kernels (HWIO, custom_layers.py:321): optional OIHW companions, see lq_fq_forward_oihw below; conv_co = 0: none */
+    float* out_oihw;     /* second forward output in OIHW order, or NULL          */
+    float* dp;           /* dP in HWIO order, written by lq_batch_scale_grad_oihw */
+    int64_t conv_hw, conv_ci, conv_co;   /* kh*kw, input channels, output channels  */
 } lq_tensor_desc;
 
 typedef struct lq_batch lq_batch;
@@ -186,6 +190,9 @@ int lq_batch_destroy(lq_batch* batch);
 size_t lq_batch_workspace_bytes(const lq_batch* batch);
 int lq_batch_forward(const lq_batch* batch, void* stream);
 int lq_batch_scale_grad(const lq_batch* batch, const float* const* dy, void* ws, size_t ws_bytes, void* stream);
+/* As lq_batch_scale_grad, but for every tensor that has an OIHW companion dy[i] is in OIHW order (MIOpen's weight gradient
+ * as it stands) and dP (= dy, custom_layers.py:118) is written in HWIO order to the descriptor's `dp` buffer.            */
+int lq_batch_scale_grad_oihw(const lq_batch* batch, const float* const* dy, void* ws, size_t ws_bytes, void* stream);
 int lq_batch_scale_adam(const lq_batch* batch, double lr, double beta1, double beta2, double eps, int64_t step,
                         const int64_t* step_dev, int mode, void* stream);
 
@@ -238,12 +245,26 @@ int lq_selftest_ratio_division(uint64_t seed, uint32_t blocks, uint32_t pairs_pe
 int lq_selftest_uniform_division(uint64_t seed, uint32_t blocks, uint32_t pairs_per_thread, uint64_t* mismatches_dev,
                                  void* stream);
 
+/* ---- conv kernels: HWIO parameter, OIHW consumer ---------------------------------------------------------------
+ * The reference keeps conv kernels in HWIO (custom_layers.py:321) and `orientation` names HWIO axes; MIOpen consumes OIHW.
+ * Instead of a separate transpose launch after K1 and another before K2 (what `qk.permute(3, 2, 0, 1)` costs in torch),
+ *   lq_fq_forward_oihw     writes out (HWIO, as lq_fq_forward) AND out_oihw[(o*ci + c)*hw + h] = out[(h*ci + c)*co + o];
+ *   lq_fq_scale_grad_oihw  takes dy in OIHW order, computes ds exactly as lq_fq_scale_grad would on the un-permuted dy
+ *                          (same traversal, same summation order: bit-identical) and writes dP = dy in HWIO order.
+ * hw = kh*kw; hw*ci*co must equal outer*G*inner.  Weight-sized tensors (below 2^32 elements).                            */
+int lq_fq_forward_oihw(const float* P, const float* s, float* out, float* out_oihw, int64_t hw, int64_t ci, int64_t co,
+                       int64_t outer, int64_t G, int64_t inner, void* stream);
+int lq_fq_scale_grad_oihw(const float* P, const float* s, const float* dy_oihw, float lambda, float* ds, float* dP,
+                          void* ws, size_t ws_bytes, int64_t hw, int64_t ci, int64_t co,
+                          int64_t outer, int64_t G, int64_t inner, void* stream);
+
 /* ---- profiling hook ----------------------------------------------------------------------
- * lq_fq_scale_grad / lq_fq_fwd_bwd_fused are two launches (traversal, finalize).  To time the traversal kernel ALONE with
- * events from outside (bench.py's roofline leg), lq_profile_mark(event) makes every such call of THIS host thread record
- * `event` (a hipEvent_t) on its stream between the two launches; lq_profile_mark(NULL) switches it off.  Nothing is
- * recorded when a call needs no finalize launch (direct emit).                                                     */
-int lq_profile_mark(void* event);
+ * lq_profile_events(start, stop): while set (both hipEvent_t, created with timing enabled), every row-stream traversal
+ * kernel this host thread launches (K1 / K2 / K4 of streaming-size tensors with rows >= 1024 elements: the BENCH path) is
+ * launched through hipExtLaunchKernelGGL with these events, which then carry the kernel's OWN begin and end timestamps --
+ * hipEventElapsedTime(start, stop) is the kernel duration rocprofv3 reports, without the cost of bracketing event records
+ * and without the finalize launch of the two-launch calls.  lq_profile_events(NULL, NULL) switches it off.            */
+int lq_profile_events(void* start, void* stop);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,8 @@ SIGNATURES = {
 class TensorDesc(ctypes.Structure):
     """lq_tensor_desc of include/lq_hip.h."""
     _fields_ = [("P", _c_p), ("s", _c_p), ("dy", _c_p), ("out", _c_p), ("ds", _c_p), ("m", _c_p), ("v", _c_p),
-                ("outer", _c_i64), ("G", _c_i64), ("inner", _c_i64), ("lambda_", _c_f), ("min_value", _c_f)]
+                ("outer", _c_i64), ("G", _c_i64), ("inner", _c_i64), ("lambda_", _c_f), ("min_value", _c_f),
+                ("out_oihw", _c_p), ("dp", _c_p), ("conv_hw", _c_i64), ("conv_ci", _c_i64), ("conv_co", _c_i64)]
 
 
 SIGNATURES.update({
@@ -64,6 +65,9 @@ SIGNATURES.update({
     "lq_batch_workspace_bytes": (_c_sz, [_c_p]),
     "lq_batch_forward": (_c_int, [_c_p, _c_p]),
     "lq_batch_scale_grad": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
+    "lq_batch_scale_grad_oihw": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
+    "lq_fq_forward_oihw": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    "lq_fq_scale_grad_oihw": (_c_int, [_c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p, _c_sz, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "lq_batch_scale_adam": (_c_int, [_c_p, _c_d, _c_d, _c_d, _c_d, _c_i64, _c_p, _c_int, _c_p]),
     "lq_batch_penalty_grads": (_c_int, [_c_p, _c_int, ctypes.POINTER(_c_f), ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
     "lq_adam_set_create": (_c_int, [ctypes.POINTER(_c_p), ctypes.POINTER(_c_p), ctypes.POINTER(_c_p), ctypes.POINTER(_c_i64),
@@ -74,7 +78,7 @@ SIGNATURES.update({
     "lq_selftest_uniform_division": (_c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _c_p, _c_p]),
     "lq_q_minmax": (_c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
     "lq_q_histogram": (_c_int, [_c_p, _c_p, ctypes.c_int32, _c_i64, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
-    "lq_profile_mark": (_c_int, [_c_p]),
+    "lq_profile_events": (_c_int, [_c_p, _c_p]),
 })
 
 _lib: Optional[ctypes.CDLL] = None

@@ -28,11 +28,12 @@ from .layers import CustomDenseLayer, _ConvBase, custom_layers_of
 
 
 class _Entry:
-    __slots__ = ("layer", "slot", "param", "nested", "out", "ds", "m", "v", "desc")
+    __slots__ = ("layer", "slot", "param", "nested", "out", "ds", "m", "v", "desc", "out_oihw", "dp", "conv")
 
 
 class FakeQuantBatch:
-    def __init__(self, model_or_layers, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-7, mode: str = "keras"):
+    def __init__(self, model_or_layers, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-7, mode: str = "keras",
+                 oihw: bool = True):
         layers = custom_layers_of(model_or_layers) if isinstance(model_or_layers, torch.nn.Module) else list(model_or_layers)
         self.layers = layers
         self._external_grads = False
@@ -65,6 +66,15 @@ class FakeQuantBatch:
                 e.m = torch.zeros_like(nested.scale.data)
                 e.v = torch.zeros_like(nested.scale.data)
                 e.desc = group_descriptor(tuple(param.shape), tuple(nested.scale.shape))
+                # conv kernels of nested-quantization layers: the forward launch also emits the OIHW tensor MIOpen consumes and
+                # the scale-gradient launch reads MIOpen's OIHW weight gradient, writing dP back in HWIO order (lq_hip.h:
+                # lq_fq_forward_oihw) -- no transposition launches around the convolutions
+                e.out_oihw = e.dp = e.conv = None
+                if oihw and slot == 0 and isinstance(layer, _ConvBase) and nested.penalty_threshold is not None:
+                    kh, kw, ci, co = (int(d) for d in param.shape)
+                    e.conv = (kh * kw, ci, co)
+                    e.out_oihw = torch.empty((co, ci, kh, kw), dtype=torch.float32, device=param.device)
+                    e.dp = torch.empty_like(param.data)
                 self.entries.append(e)
         if not self.entries:
             raise ValueError("no custom layers")
@@ -78,7 +88,8 @@ class FakeQuantBatch:
             arr[i] = _hip.TensorDesc(e.param.data_ptr(), e.nested.scale.data_ptr(), None, e.out.data_ptr(), e.ds.data_ptr(),
                                      e.m.data_ptr(), e.v.data_ptr(), e.desc[0], e.desc[1], e.desc[2],
                                      float("nan") if lam is None else float(lam),
-                                     float(c.min_value) if c is not None else float("-inf"))
+                                     float(c.min_value) if c is not None else float("-inf"),
+                                     _hip.ptr(e.out_oihw), _hip.ptr(e.dp), *(e.conv or (0, 0, 0)))
         handle = ctypes.c_void_p()
         _hip.check(lib.lq_batch_create(arr, n, ctypes.byref(handle)), "lq_batch_create")
         self._handle = handle
@@ -93,6 +104,8 @@ class FakeQuantBatch:
         for i, e in enumerate(self.entries):
             slots.setdefault(id(e.layer), [e.layer, None, None])[1 + e.slot] = i
         self._layer_slots = list(slots.values())
+        self._oihw_idx = [i for i, e in enumerate(self.entries) if e.out_oihw is not None]     # extra autograd outputs, in this order
+        self._oihw_pos = {i: len(self.entries) + k for k, i in enumerate(self._oihw_idx)}
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -114,10 +127,12 @@ class FakeQuantBatch:
         """One launch: fake-quantise every kernel/bias; layers pick the results up in their next call."""
         self._check_pointers()
         outs = _BatchFn.apply(self, *self._flat)
+        n = len(self.entries)
         for layer, ik, ib in self._layer_slots:
             # plain instance attribute (not a Parameter/Module): written through __dict__, nn.Module.__setattr__ costs ~3 us
-            layer.__dict__["_q_pre"] = (None if ik is None else outs[ik], None if ib is None else outs[ib])
-        return outs
+            layer.__dict__["_q_pre"] = (None if ik is None else outs[ik], None if ib is None else outs[ib],
+                                        outs[self._oihw_pos[ik]] if ik in self._oihw_pos else None)
+        return outs[:n]
 
     # ------------------------------------------------------------------ exact data-parallel mode (ddp.py, mode B)
     def scale_grads_from_param_grads(self):
@@ -188,29 +203,52 @@ class _BatchFn(torch.autograd.Function):
         lib = _hip.load()
         _hip.check(lib.lq_batch_forward(batch._handle, _hip.stream_ptr(batch.device)), "lq_batch_forward")
         ctx.batch = batch
-        return tuple(e.out.detach() for e in batch.entries)      # fresh tensor objects over the static buffers
+        # fresh tensor objects over the static buffers: every HWIO output, then the OIHW companions of the conv kernels
+        return tuple(e.out.detach() for e in batch.entries) + tuple(batch.entries[i].out_oihw.detach() for i in batch._oihw_idx)
 
     @staticmethod
     def backward(ctx, *dys):
         batch: FakeQuantBatch = ctx.batch
         lib = _hip.load()
+        n = len(batch.entries)
+        # a conv kernel with an OIHW companion: its consumer (the convolution) used the companion, so the gradient arrives there,
+        # in OIHW order; a consumer that used the HWIO output instead is served by the plain path below
+        dys = list(dys)
+        oihw_used = False
+        for i in batch._oihw_idx:
+            d_o = dys[batch._oihw_pos[i]]
+            if d_o is not None:
+                if dys[i] is not None:
+                    raise RuntimeError("FakeQuantBatch: both the HWIO and the OIHW output of one conv kernel received a gradient")
+                oihw_used = True
         if batch.defer_scale_grads:          # dP == dy (custom_layers.py:118); ds follows after the all-reduce
             grads = [None]
-            for e, d in zip(batch.entries, dys):
+            for i, e in enumerate(batch.entries):
+                d = dys[i]
+                if d is None and i in batch._oihw_pos and dys[batch._oihw_pos[i]] is not None:
+                    d = dys[batch._oihw_pos[i]].permute(2, 3, 1, 0)
                 grads.extend((d if d is not None else torch.zeros_like(e.out), None))
             return tuple(grads)
         keep = []
-        for i, (e, d) in enumerate(zip(batch.entries, dys)):
-            if d is None:
+        gathered = set()
+        for i, e in enumerate(batch.entries):
+            d = dys[i]
+            if d is None and i in batch._oihw_pos and dys[batch._oihw_pos[i]] is not None:
+                d = dys[batch._oihw_pos[i]]
+                gathered.add(i)
+            elif d is None:
                 d = torch.zeros_like(e.out)
+            elif oihw_used and i in batch._oihw_pos:
+                raise RuntimeError("FakeQuantBatch: conv kernels must all be consumed through the same layout in one step")
             d = _hip.require_device_f32(d, "dy")
             keep.append(d)
             batch._ptrs[i] = d.data_ptr()
-        _hip.check(lib.lq_batch_scale_grad(batch._handle, batch._ptrs, _hip.ptr(batch.ws), batch.ws.numel(),
-                                           _hip.stream_ptr(batch.device)), "lq_batch_scale_grad")
+        fn = lib.lq_batch_scale_grad_oihw if oihw_used else lib.lq_batch_scale_grad
+        _hip.check(fn(batch._handle, batch._ptrs, _hip.ptr(batch.ws), batch.ws.numel(), _hip.stream_ptr(batch.device)),
+                   "lq_batch_scale_grad")
         grads = [None]
-        for e, d in zip(batch.entries, keep):
-            grads.append(d)                                        # dP is dy itself (custom_layers.py:118)
+        for i, (e, d) in enumerate(zip(batch.entries, keep)):
+            grads.append(e.dp if i in gathered else d)             # dP is dy itself (custom_layers.py:118), in HWIO order
             if e.nested.penalty_threshold is not None:
                 g = e.nested.scale.grad
                 if g is not None and not batch._external_grads:

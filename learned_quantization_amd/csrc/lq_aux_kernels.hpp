@@ -107,27 +107,65 @@ __global__ void k_min_project(float* w, int64_t n, float min_value) {
 }
 
 // result[a, b] = max over the middle axis of |floor(P/s)| for a tensor viewed (pre, n_axis, post)
-__global__ void k_q_absmax_axis(const float* P, const float* s, float* result, int64_t pre, int64_t n_axis, int64_t post,
-                                int64_t G, int64_t inner) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= pre * post) return;
-    const int64_t a = t / post, b = t - a * post;
-    uint32_t best = 0u;
-    for (int64_t k = 0; k < n_axis; ++k) {
-        const int64_t i = (a * n_axis + k) * post + b;
-        Ctx c;
-        c.s = s[(i / inner) % G];
-        c.r = 0.f;
-        c.fast = 0;
-        c.lam_hi = 0.f;
-        c.sure_ok = 0;
-        c.k0 = c.k1 = 0.f;
-        float q, o;
-        fq_core(P[i], c, q, o);
-        const uint32_t bits = __float_as_uint(fabsf(q));
-        best = bits > best ? bits : best;
+// (custom_callbacks.py:98-99: np.max(np.abs(floor(k/s)), axis=1)).  The tensor is walked as a flat stream -- lane l of a
+// wave reads element c0 + l: every load is one coalesced 256-byte access whatever the reduced axis is -- in blocks of
+// kAbsChunk consecutive elements.  |q| >= 0, so the maximum is taken on the uint32 bit pattern with INTEGER atomics: exact
+// and independent of arrival order.  A block first folds its chunk into an LDS table (the outputs a chunk can touch span
+// at most (chunk / (n_axis*post) + 2) * post entries); a wave whose 64 elements all belong to one output (post == 1 with
+// a long axis: Dense (in, out) reduced over `out`) folds them with a shuffle reduction and issues one atomic.  Entries that
+// stayed 0 are not flushed (the caller's result buffer is zeroed by the same ABI call).  IT: 32-bit indices below 2^32
+// elements (a 64-bit div/mod per element used to dominate this kernel).
+constexpr int kAbsChunk = kBlock * 16;
+constexpr int kAbsTab = 4096;
+
+template <typename IT>
+__global__ __launch_bounds__(kBlock) void k_q_absmax_axis(const float* __restrict__ P, const float* __restrict__ s, uint32_t* result,
+                                                          IT n, IT n_axis, IT post, IT G, IT inner, int use_lds, int span) {
+    __shared__ uint32_t tab[kAbsTab];
+    const IT c0 = (IT)blockIdx.x * (IT)kAbsChunk;
+    const IT slice = n_axis * post;
+    const IT o_base = (c0 / slice) * post;
+    if (use_lds) {
+        for (int t = threadIdx.x; t < span; t += kBlock) tab[t] = 0u;
+        __syncthreads();
     }
-    result[t] = __uint_as_float(best);
+    float x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {                      // all loads first: 16 independent coalesced accesses in flight
+        const IT i = c0 + (IT)(u * kBlock) + (IT)threadIdx.x;
+        x[u] = P[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const IT i = c0 + (IT)(u * kBlock) + (IT)threadIdx.x;
+        const bool valid = i < n;
+        const IT ic = valid ? i : n - 1;
+        const float q = floorf(x[u] / s[(ic / inner) % G]);             // custom_layers.py:56-59 (IEEE division, floor)
+        uint32_t bits = valid ? __float_as_uint(fabsf(q)) : 0u;         // NaN compares above every finite value: it propagates like np.max
+        const IT a = ic / slice;
+        const IT o = a * post + (ic - a * slice) % post;
+        const IT o0 = __shfl(o, 0, 64);
+        if (__all(o == o0)) {                                           // the whole wave feeds one output
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t other = __shfl_xor(bits, off, 64);
+                bits = other > bits ? other : bits;
+            }
+            if ((threadIdx.x & 63) == 0 && bits) {
+                if (use_lds) atomicMax(&tab[(int)(o - o_base)], bits);
+                else atomicMax(&result[o], bits);
+            }
+        } else if (bits) {
+            if (use_lds) atomicMax(&tab[(int)(o - o_base)], bits);
+            else atomicMax(&result[o], bits);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < span; t += kBlock) {
+            const uint32_t v = tab[t];
+            if (v) atomicMax(&result[o_base + (IT)t], v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@ namespace lq {
 struct Task {
     Params p;                 // pa/pb/pc are rebound to the batch workspace inside the kernel
     float* ds;                // scale gradient output [G]
+    float* dp;                // dP in HWIO order (conv kernels with an OIHW companion), else NULL
     float* mb;                // batch-owned per-group max(|P|/s)      (MaxBin penalty)
     uint32_t* ties;           // batch-owned per-group tie counts
     int mode, vec, lpr_log2, pad0;
@@ -51,7 +52,8 @@ struct CoefPack {           // per-tensor upstream coefficient of a penalty term
 };
 
 // use_pack: 0 = pointers from the task table; 1 = pk.dy[] are the upstream gradients (scale-gradient pass);
-//           2 = penalty pass: pk.dy[] are the gradient buffers to ACCUMULATE into, cf.c[] the upstream coefficients
+//           2 = penalty pass: pk.dy[] are the gradient buffers to ACCUMULATE into, cf.c[] the upstream coefficients;
+//           3 = as 1, but the gradients of conv kernels with an OIHW companion arrive in OIHW order (OP_BWD_PERM)
 template <int OP>
 __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restrict__ tasks, int ntasks, uint32_t* ws, PtrPack pk,
                                                            int use_pack, CoefPack cf) {
@@ -59,6 +61,15 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
     const Task& t = tasks[ti];
     Params p = t.p;
     if (use_pack == 1) p.dy = pk.dy[ti];
+    if (use_pack == 3) {
+        if (p.perm_co) {
+            p.dy_perm = pk.dy[ti];
+            p.dy = p.P;               // the traversals' unconditional dy loads need a valid address; the op gathers from dy_perm
+            p.dp_out = t.dp;
+        } else {
+            p.dy = pk.dy[ti];
+        }
+    }
     if (use_pack == 2) {
         p.out = const_cast<float*>(pk.dy[ti]);
         p.accum = 1;

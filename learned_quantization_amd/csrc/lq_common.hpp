@@ -43,7 +43,21 @@ struct Params {
     float* e0;           // ds[G]
     float* e1;           // optional parts[3*G]
     double ecount;       // elements per group
+    // conv kernels: the parameter is HWIO (custom_layers.py:321), MIOpen consumes OIHW.  Element i = (h*ci + c)*co + o of the
+    // HWIO tensor (h = kh*KW + kw) is element (o*ci + c)*hw + h of the OIHW one.  K1 can emit the OIHW tensor next to
+    // `out`; K2 can take the upstream gradient in OIHW order and write dP (= dy, custom_layers.py:118) back in HWIO order.
+    float* out_perm;       // K1: second output in OIHW order, or NULL
+    const float* dy_perm;  // K2: upstream gradient in OIHW order (then `dy` is only a valid dummy), or NULL
+    float* dp_out;         // K2: dP in HWIO order, written when dy_perm is set
+    uint32_t perm_hw, perm_ci, perm_co;
 };
+
+__device__ __forceinline__ uint32_t perm_index(const Params& p, int64_t i) {      // conv kernels are far below 2^32 elements
+    const uint32_t iu = (uint32_t)i;
+    const uint32_t t = iu / p.perm_co, o = iu - t * p.perm_co;
+    const uint32_t h = t / p.perm_ci, c = t - h * p.perm_ci;
+    return (o * p.perm_ci + c) * p.perm_hw + h;
+}
 
 // Per-group context, loaded once per row / column.
 struct Ctx {
@@ -75,6 +89,8 @@ enum OpKind {
     OP_DIFF_FWD = 5,   // K5b
     OP_DIFF_BWD = 6,
     OP_QONLY = 7,      // integer view only (callbacks / export)
+    OP_FWD_PERM = 8,   // K1 that can also emit the OIHW companion of an HWIO conv kernel
+    OP_BWD_PERM = 9,   // K2 that can take dy in OIHW order and write dP in HWIO order
 };
 
 }  // namespace lq

@@ -31,6 +31,7 @@
 //   penalties         CIFAR-10/custom_loss_terms/custom_components/custom_loss_functions.py:75-116,161-195,240-275
 //   constraint        custom_layers.py:35-46
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <stdint.h>
@@ -51,6 +52,12 @@ namespace lq {
 //  Host side: plan, launchers, C ABI.
 // ------------------------------------------------------------------------------------------
 enum Mode { MODE_ROW_BIG = 0, MODE_ROW_SMALL = 1, MODE_COL = 2 };
+
+// Rows per block of the pipelined column tile, by operation (MI355X sweep, profiles/r02/column_tile_rows_per_block.txt):
+// the read-only scale-gradient traversal wants long blocks (128 rows: 5.7-5.9 TB/s; 32 rows: 4.5), the kernels that
+// also store want short ones (48 rows: K4 5.6-5.8 TB/s; 128 rows: 5.3-5.5)
+constexpr int64_t kColRbFused = 48;
+constexpr int64_t kColRbBwd = 128;
 
 struct Plan {
     int mode;
@@ -119,10 +126,10 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
                 RB = ceil_div(outer * ceil_div(C, 256), 512);
                 RB = ceil_div(RB, 16) * 16;
                 if (RB > 128) RB = 128;
-                if (const char* e = getenv("LQ_TUNE_COL_RB")) {   // development knob (tools/): rows per block of the column tile
-                    const int v = atoi(e);
-                    if (v >= 8 && (double)outer * (double)C >= (double)kPeriodic4Min) RB = v;
-                }
+                // streaming sizes with float4 columns: the round-2 pipelined tile (lq_stream2.hpp) picks its rows per block per
+                // operation at launch (kColRbFused / kColRbBwd); the plan carries the smaller one, i.e. the larger partial
+                // count, so the workspace bound holds for both
+                if ((double)outer * (double)C >= (double)kPeriodic4Min && C % 4 == 0) RB = kColRbFused;
             }
             if (RB > outer) RB = outer;
             if (!nby) nby = ceil_div(outer, RB);
@@ -187,7 +194,7 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
 }
 
 static thread_local char g_err[512] = "";
-static thread_local hipEvent_t g_mark = nullptr;      // lq_profile_mark
+static thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;      // lq_profile_events
 
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -280,6 +287,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     using O = OpT<OP>;
     const double numel = (double)p.outer * (double)p.G * (double)p.inner;
     if (numel < (double)kPeriodic4Min || pl.mode == MODE_ROW_BIG) return 0;
+    if (p.out_perm || p.dy_perm) return 0;
     const bool al16 = aligned(p.P, 16) && (!O::kDy || aligned(p.dy, 16)) && (!O::kStore || aligned(p.out, 16));
     if (!al16) return 0;
     static const int off = tune_int("LQ_TUNE_S2", 0);
@@ -332,23 +340,41 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                 }
             }
             if (nt && per == 11) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1, 256>), dim3((unsigned)pl.ysplit), dim3(256), 0, st, p, (int)pl.C, pl.ysplit);
+            else if (nt && per == 21) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 2, 256>), dim3((unsigned)pl.ysplit), dim3(256), 0, st, p, (int)pl.C, pl.ysplit);
+            else if (nt && per == 41) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 4, 256>), dim3((unsigned)pl.ysplit), dim3(256), 0, st, p, (int)pl.C, pl.ysplit);
+            // K4 with C >= 16: one float4 per stream in flight (98 VGPRs, 5 waves per SIMD) measured 5.67-5.75 TB/s at C = 64 against
+            // 5.30-5.49 with two (128 VGPRs); at C = 3 the other way round (5.57 against 5.24)
+            else if (nt && OP == OP_FUSED && pl.C >= 16) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             else if (nt) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             return check_hip("periodic column launch") ? -1 : 1;
         }
         if ((off & 2) || pl.C % 4 != 0) return 0;
         const int64_t nbx = ceil_div(pl.C, 256);
+        {
+            // rows per block by operation; never fewer than the plan's (the workspace was sized for the plan's partial count)
+            static const int64_t rb_bwd = tune_int("LQ_TUNE_COL_RB_K2", (int)kColRbBwd), rb_st = tune_int("LQ_TUNE_COL_RB_K4", (int)kColRbFused);
+            int64_t rb = (OP == OP_BWD) ? rb_bwd : rb_st;
+            if (rb < pl.rps) rb = pl.rps;
+            if (rb > p.outer) rb = p.outer;
+            const int64_t nby = ceil_div(p.outer, rb);
+            pl.rps = rb;                      // the finalize that follows must walk the partial layout this launch produces
+            pl.ysplit = nby;
+            pl.np = nby * pl.C;
+            pl.n1 = nby;
+        }
         const int64_t blocks = nbx * pl.ysplit;
         if (blocks > 2147483647ll) return 0;
-        static const int pipe_r = tune_int("LQ_TUNE_PIPE", 24);      // U*10 + NW (scale-gradient ops)
-        static const int pipe_f = tune_int("LQ_TUNE_PIPE_FWD", 24);
+        static const int pipe_r = tune_int("LQ_TUNE_PIPE", 28);      // U*10 + NW (scale-gradient ops)
+        static const int pipe_f = tune_int("LQ_TUNE_PIPE_FWD", 28);
         const int pipe = (OP == OP_FWD) ? pipe_f : pipe_r;
 #define LQ_PIPE(NT_, U_, NW_) hipLaunchKernelGGL((k_col_pipe<OP, NT_, U_, NW_>), dim3((unsigned)blocks), dim3(NW_ * 64), 0, st, p, pl.C, pl.rps, nbx)
         if (nt) {
             if (pipe == 14) LQ_PIPE(1, 1, 4); else if (pipe == 44) LQ_PIPE(1, 4, 4); else if (pipe == 28) LQ_PIPE(1, 2, 8);
-            else if (pipe == 18) LQ_PIPE(1, 1, 8); else if (pipe == 48) LQ_PIPE(1, 4, 8); else LQ_PIPE(1, 2, 4);
+            else if (pipe == 18) LQ_PIPE(1, 1, 8); else if (pipe == 48) LQ_PIPE(1, 4, 8); else if (pipe == 24) LQ_PIPE(1, 2, 4);
+            else LQ_PIPE(1, 2, 8);
         } else {
-            LQ_PIPE(0, 2, 4);
+            LQ_PIPE(0, 2, 8);
         }
 #undef LQ_PIPE
         return check_hip("pipelined column launch") ? -1 : 1;
@@ -410,7 +436,7 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         if (u2) {
             const int64_t nc2 = row_chunks(pl.L, (int64_t)pl.bs * 8);
             const dim3 grid2 = grid3d ? dim3((unsigned)nc2, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)(pl.R * nc2));
-            hipLaunchKernelGGL((k_row_stream<OP, 4, 512, 1, 2>), grid2, dim3(512), 0, st, p, pl.L, nc2, grid3d);
+            hipExtLaunchKernelGGL((k_row_stream<OP, 4, 512, 1, 2>), grid2, dim3(512), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, nc2, grid3d);
             // the finalize that follows must walk the partial layout this launch produced
             pl.CH = pl.bs * 8;
             pl.nc = nc2;
@@ -420,8 +446,10 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
             pl.n2 = nc2;
             return check_hip("traversal launch");
         }
+        // hipExtLaunchKernelGGL with NULL events is a plain launch; with lq_profile_events() set, the events take the kernel's own
+        // begin / end timestamps (what rocprofv3 reports as its duration)
 #define LQ_LAUNCH_STREAM(VEC_, BS_, NT_) \
-        hipLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_>), grid, dim3(BS_), 0, st, p, pl.L, pl.nc, grid3d)
+        hipExtLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_>), grid, dim3(BS_), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, pl.nc, grid3d)
         if (vec) {
             if (pl.bs == 1024) {
                 if (nt) LQ_LAUNCH_STREAM(4, 1024, 1);
@@ -460,7 +488,7 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
 template <int OP>
 static int launch_finalize(const Params& p, FinGeom f, hipStream_t st) {
     const int64_t n = f.n1 * f.n2;
-    if (g_mark) (void)hipEventRecord(g_mark, st);
+
     // one thread per group walks its partials one after the other: right for very many groups (throughput) or a handful of
     // partials, a latency trap otherwise (32 partials: ~10 us) -- few groups get one wave each instead
     if (n <= 4 || (n <= 32 && f.groups >= 2048)) {
@@ -524,8 +552,9 @@ extern "C" {
 
 int lq_version(void) { return LQ_ABI_VERSION; }
 
-int lq_profile_mark(void* event) {
-    g_mark = (hipEvent_t)event;
+int lq_profile_events(void* start, void* stop) {
+    g_prof_start = (hipEvent_t)start;
+    g_prof_stop = (hipEvent_t)stop;
     return LQ_OK;
 }
 
@@ -566,6 +595,69 @@ int lq_fq_forward(const float* P, const float* s, float* out, void* q, int q_dty
         return launch_traverse<OP_FWD>(pl, p, (hipStream_t)stream);
     }
     return launch_traverse<OP_QONLY>(pl, p, (hipStream_t)stream);
+}
+
+static int check_conv(const char* fn, int64_t hw, int64_t ci, int64_t co, int64_t outer, int64_t G, int64_t inner) {
+    if (hw <= 0 || ci <= 0 || co <= 0) return fail(LQ_EINVAL, "%s: hw, ci, co must be positive", fn);
+    const double n = (double)hw * (double)ci * (double)co;
+    if (n != (double)outer * (double)G * (double)inner) return fail(LQ_EINVAL, "%s: hw*ci*co does not match the tensor", fn);
+    if (n >= 4294967296.0) return fail(LQ_EINVAL, "%s: conv kernels must have fewer than 2^32 elements", fn);
+    return LQ_OK;
+}
+
+int lq_fq_forward_oihw(const float* P, const float* s, float* out, float* out_oihw, int64_t hw, int64_t ci, int64_t co,
+                       int64_t outer, int64_t G, int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    if ((rc = check_conv("lq_fq_forward_oihw", hw, ci, co, outer, G, inner))) return rc;
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(out);
+    LQ_REQUIRE_PTR(out_oihw);
+    Plan pl = make_plan(outer, G, inner);
+    Params p = base_params(P, s, outer, G, inner);
+    p.out = out;
+    p.out_perm = out_oihw;
+    p.perm_hw = (uint32_t)hw;
+    p.perm_ci = (uint32_t)ci;
+    p.perm_co = (uint32_t)co;
+    return launch_traverse<OP_FWD_PERM>(pl, p, (hipStream_t)stream);
+}
+
+int lq_fq_scale_grad_oihw(const float* P, const float* s, const float* dy_oihw, float lambda, float* ds, float* dP,
+                          void* ws, size_t ws_bytes, int64_t hw, int64_t ci, int64_t co,
+                          int64_t outer, int64_t G, int64_t inner, void* stream) {
+    int rc = check_desc(outer, G, inner);
+    if (rc) return rc;
+    if ((rc = check_conv("lq_fq_scale_grad_oihw", hw, ci, co, outer, G, inner))) return rc;
+    LQ_REQUIRE_PTR(P);
+    LQ_REQUIRE_PTR(s);
+    LQ_REQUIRE_PTR(dy_oihw);
+    LQ_REQUIRE_PTR(ds);
+    LQ_REQUIRE_PTR(dP);
+    Plan pl = make_plan(outer, G, inner);
+    Params p = base_params(P, s, outer, G, inner);
+    p.dy = P;                     // valid dummy for the traversals' dy loads; the op gathers from dy_perm
+    p.dy_perm = dy_oihw;
+    p.dp_out = dP;
+    p.perm_hw = (uint32_t)hw;
+    p.perm_ci = (uint32_t)ci;
+    p.perm_co = (uint32_t)co;
+    p.lam = lambda;
+    p.tmode = (lambda < 4.0e-4f) ? 0 : ((lambda <= 0.25f) ? 1 : 2);
+    if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
+    const bool direct = pl.n1 * pl.n2 == 1;
+    if (direct) {
+        p.direct = 1;
+        p.e0 = ds;
+        p.e1 = nullptr;
+        p.ecount = (double)outer * (double)inner;
+    }
+    if ((rc = launch_traverse<OP_BWD_PERM>(pl, p, (hipStream_t)stream))) return rc;
+    if (direct) return LQ_OK;
+    FinGeom f = group_geom(pl, outer, G, inner);
+    f.o0 = ds;
+    return launch_finalize<OP_BWD>(p, f, (hipStream_t)stream);
 }
 
 int lq_fq_scale_grad(const float* P, const float* s, const float* dy, float lambda, float* ds, float* parts, void* ws,
@@ -781,7 +873,22 @@ int lq_q_absmax_over_axis(const float* P, const float* s, float* result, int64_t
     LQ_REQUIRE_PTR(P);
     LQ_REQUIRE_PTR(s);
     LQ_REQUIRE_PTR(result);
-    hipLaunchKernelGGL(k_q_absmax_axis, dim3((unsigned)ceil_div(pre * post, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, P, s, result, pre, n_axis, post, G, inner);
+    const int64_t n = pre * n_axis * post;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(result, 0, (size_t)(pre * post) * sizeof(float), st) != hipSuccess) return check_hip("absmax axis memset");
+    const int64_t blocks = ceil_div(n, (int64_t)kAbsChunk);
+    if (blocks > 2147483647ll) return fail(LQ_EINVAL, "lq_q_absmax_over_axis: tensor too large");
+    // outputs one chunk can touch: (chunks of slices it overlaps) * post entries, starting at its first slice
+    const int64_t slice = n_axis * post;
+    int64_t span = (ceil_div((int64_t)kAbsChunk, slice) + 1) * post;
+    if (span > pre * post) span = pre * post;
+    const int use_lds = span <= kAbsTab ? 1 : 0;
+    if (n < 4294967296ll)
+        hipLaunchKernelGGL(k_q_absmax_axis<uint32_t>, dim3((unsigned)blocks), dim3(kBlock), 0, st, P, s, reinterpret_cast<uint32_t*>(result),
+                           (uint32_t)n, (uint32_t)n_axis, (uint32_t)post, (uint32_t)G, (uint32_t)inner, use_lds, (int)(use_lds ? span : 0));
+    else
+        hipLaunchKernelGGL(k_q_absmax_axis<int64_t>, dim3((unsigned)blocks), dim3(kBlock), 0, st, P, s, reinterpret_cast<uint32_t*>(result),
+                           n, n_axis, post, G, inner, use_lds, (int)(use_lds ? span : 0));
     return check_hip("absmax axis launch");
 }
 
@@ -803,6 +910,7 @@ struct lq_batch {
     lq::AdamTask* adam_d = nullptr;
     uint32_t fwd_blocks = 0, bwd_blocks = 0, bwd_groups = 0, pen_blocks = 0, pen_groups = 0;
     size_t ws_bytes = 256;
+    bool has_perm = false;               // some conv kernel has an OIHW companion
 };
 
 namespace lq {
@@ -815,6 +923,13 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, uint32_t& block
     t.p.dy = d.dy;
     t.p.lam = d.lambda;
     t.p.tmode = (d.lambda < 4.0e-4f) ? 0 : ((d.lambda <= 0.25f) ? 1 : 2);
+    if (d.conv_co > 0) {
+        t.p.out_perm = bwd ? nullptr : d.out_oihw;
+        t.p.perm_hw = (uint32_t)d.conv_hw;
+        t.p.perm_ci = (uint32_t)d.conv_ci;
+        t.p.perm_co = (uint32_t)d.conv_co;
+        t.dp = d.dp;
+    }
     t.ds = d.ds;
     t.mode = pl.mode;
     t.lpr_log2 = pl.lpr_log2;
@@ -874,6 +989,12 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
         int rc = check_desc(d.outer, d.G, d.inner);
         if (!rc && (!d.P || !d.s || !d.out)) rc = fail(LQ_EINVAL, "lq_batch_create: tensor %d has a NULL P/s/out", i);
         if (!rc && (!aligned(d.P, 4) || !aligned(d.s, 4) || !aligned(d.out, 4))) rc = fail(LQ_EALIGN, "lq_batch_create: tensor %d misaligned", i);
+        if (!rc && d.conv_co > 0) {
+            rc = check_conv("lq_batch_create", d.conv_hw, d.conv_ci, d.conv_co, d.outer, d.G, d.inner);
+            if (!rc && (!d.out_oihw || !d.dp || !aligned(d.out_oihw, 4) || !aligned(d.dp, 4)))
+                rc = fail(LQ_EINVAL, "lq_batch_create: tensor %d has conv extents but no out_oihw / dp buffer", i);
+            if (!rc) b->has_perm = true;
+        }
         Task t;
         if (!rc) rc = fill_task(t, d, false, b->fwd_blocks, gp_dummy, dummy);
         if (rc) {
@@ -970,8 +1091,12 @@ int lq_batch_forward(const lq_batch* b, void* stream) {
     if (!b) return fail(LQ_EINVAL, "lq_batch_forward: NULL batch");
     PtrPack pk;
     CoefPack cf;
-    hipLaunchKernelGGL((k_batch_traverse<OP_FWD>), dim3(b->fwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->fwd_d,
-                       (int)b->fwd_h.size(), (uint32_t*)nullptr, pk, 0, cf);
+    if (b->has_perm)
+        hipLaunchKernelGGL((k_batch_traverse<OP_FWD_PERM>), dim3(b->fwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->fwd_d,
+                           (int)b->fwd_h.size(), (uint32_t*)nullptr, pk, 0, cf);
+    else
+        hipLaunchKernelGGL((k_batch_traverse<OP_FWD>), dim3(b->fwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->fwd_d,
+                           (int)b->fwd_h.size(), (uint32_t*)nullptr, pk, 0, cf);
     return check_hip("batch forward launch");
 }
 
@@ -983,7 +1108,19 @@ static bool batch_wide_finalize(const std::vector<lq::Task>& h) {
 }
 extern "C" {
 
+static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream, bool oihw);
+
 int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream) {
+    return batch_scale_grad(b, dy, ws, ws_bytes, stream, false);
+}
+
+int lq_batch_scale_grad_oihw(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream) {
+    return batch_scale_grad(b, dy, ws, ws_bytes, stream, b && b->has_perm);
+}
+
+}  // extern "C"
+
+static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream, bool oihw) {
     if (!b) return fail(LQ_EINVAL, "lq_batch_scale_grad: NULL batch");
     if (b->bwd_h.empty()) return LQ_OK;
     if (!ws) return fail(LQ_EWORKSPACE, "lq_batch_scale_grad: workspace is NULL (need %zu bytes)", b->ws_bytes);
@@ -996,15 +1133,20 @@ int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, siz
         const float* d = dy ? dy[b->bwd_index[i]] : b->bwd_h[i].p.dy;
         if (!d) return fail(LQ_EINVAL, "lq_batch_scale_grad: no upstream gradient for tensor %d", b->bwd_index[i]);
         if (!aligned(d, 4)) return fail(LQ_EALIGN, "lq_batch_scale_grad: dy of tensor %d misaligned", b->bwd_index[i]);
-        if (((b->bwd_h[i].mode != MODE_COL && b->bwd_h[i].vec) || (b->bwd_h[i].mode == MODE_COL && b->bwd_h[i].col_variant >= 4)) &&
+        const bool gathered = oihw && b->bwd_h[i].p.perm_co != 0;      // read element-wise through the permutation: no vector loads
+        if (!gathered && ((b->bwd_h[i].mode != MODE_COL && b->bwd_h[i].vec) || (b->bwd_h[i].mode == MODE_COL && b->bwd_h[i].col_variant >= 4)) &&
             !aligned(d, 16))
             all_aligned = false;
         pk.dy[i] = d;
     }
     if (!all_aligned) return fail(LQ_EALIGN, "lq_batch_scale_grad: a 16-byte aligned tensor got a dy that is not 16-byte aligned");
     CoefPack cf;
-    hipLaunchKernelGGL((k_batch_traverse<OP_BWD>), dim3(b->bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->bwd_d,
-                       (int)b->bwd_h.size(), (uint32_t*)ws, pk, 1, cf);
+    if (oihw)
+        hipLaunchKernelGGL((k_batch_traverse<OP_BWD_PERM>), dim3(b->bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->bwd_d,
+                           (int)b->bwd_h.size(), (uint32_t*)ws, pk, 3, cf);
+    else
+        hipLaunchKernelGGL((k_batch_traverse<OP_BWD>), dim3(b->bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->bwd_d,
+                           (int)b->bwd_h.size(), (uint32_t*)ws, pk, 1, cf);
     int rc = check_hip("batch scale-grad launch");
     if (rc) return rc;
     if (batch_wide_finalize(b->bwd_h))
@@ -1015,6 +1157,8 @@ int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, siz
                            (int)b->bwd_h.size(), (uint32_t*)ws, 0);
     return check_hip("batch finalize launch");
 }
+
+extern "C" {
 
 int lq_batch_penalty_grads(const lq_batch* b, int kind, const float* coeff, float* const* grad, void* ws, size_t ws_bytes,
                            void* stream) {

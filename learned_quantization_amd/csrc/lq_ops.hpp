@@ -45,40 +45,55 @@ struct OpBase {
     }
 };
 
-template <>
-struct OpT<OP_FWD> : OpBase {
+// PERM = true: the variant that can also emit the OIHW companion of an HWIO conv kernel (used by the multi-tensor batch and
+// the *_oihw entry points only: the streaming kernels of the BENCH path keep the lean instantiation)
+template <bool PERM>
+struct FwdOp : OpBase {
     static constexpr bool kStore = true;
+    __device__ static __forceinline__ void side4(const Params& p, int64_t i, const float4& q, const float4& o) {
+        if (p.q) {
+            store_q(p.q, p.q_dtype, i + 0, q.x);
+            store_q(p.q, p.q_dtype, i + 1, q.y);
+            store_q(p.q, p.q_dtype, i + 2, q.z);
+            store_q(p.q, p.q_dtype, i + 3, q.w);
+        }
+        if constexpr (PERM) {
+            if (p.out_perm) {                   // the OIHW companion of an HWIO conv kernel (weight-sized tensors)
+                p.out_perm[perm_index(p, i + 0)] = o.x;
+                p.out_perm[perm_index(p, i + 1)] = o.y;
+                p.out_perm[perm_index(p, i + 2)] = o.z;
+                p.out_perm[perm_index(p, i + 3)] = o.w;
+            }
+        }
+    }
     __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float, Acc&) {
         float q, o;
         fq_core(x, c, q, o);
         if (p.q) store_q(p.q, p.q_dtype, i, q);
+        if constexpr (PERM) {
+            if (p.out_perm) p.out_perm[perm_index(p, i)] = o;
+        }
         return o;
     }
     static constexpr bool kVec4 = true;
     __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t i, const float4& x, const float4&, Acc&) {
         float4 q, o;
         fq_core4(x, c, q, o);
-        if (p.q) {
-            store_q(p.q, p.q_dtype, i + 0, q.x);
-            store_q(p.q, p.q_dtype, i + 1, q.y);
-            store_q(p.q, p.q_dtype, i + 2, q.z);
-            store_q(p.q, p.q_dtype, i + 3, q.w);
-        }
+        side4(p, i, q, o);
         return o;
     }
     static constexpr bool kVec4c = true;
     __device__ static __forceinline__ float4 elem4c(const Params& p, const Ctx* c, int64_t i, const float4& x, const float4&, Acc*) {
         float4 q, o;
         fq_core4c(x, c, q, o);
-        if (p.q) {
-            store_q(p.q, p.q_dtype, i + 0, q.x);
-            store_q(p.q, p.q_dtype, i + 1, q.y);
-            store_q(p.q, p.q_dtype, i + 2, q.z);
-            store_q(p.q, p.q_dtype, i + 3, q.w);
-        }
+        side4(p, i, q, o);
         return o;
     }
 };
+template <>
+struct OpT<OP_FWD> : FwdOp<false> {};
+template <>
+struct OpT<OP_FWD_PERM> : FwdOp<true> {};
 
 template <>
 struct OpT<OP_QONLY> : OpBase {
@@ -90,31 +105,57 @@ struct OpT<OP_QONLY> : OpBase {
     }
 };
 
-template <>
-struct OpT<OP_BWD> : OpBase {
+template <bool PERM>
+struct BwdOp : OpBase {
     static constexpr bool kDy = true;
     static constexpr bool kReduce = true;
-    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t, float x, float dy, Acc& acc) {
+    // upstream gradient of an HWIO conv kernel that arrives in OIHW order (MIOpen's weight gradient): gathered here, and
+    // handed back in HWIO order as dP (dP == dy, custom_layers.py:118) -- weight-sized tensors, L2-resident
+    __device__ static __forceinline__ float gather1(const Params& p, int64_t i) {
+        const float d = p.dy_perm[perm_index(p, i)];
+        p.dp_out[i] = d;
+        return d;
+    }
+    __device__ static __forceinline__ float4 gather4(const Params& p, int64_t i) {
+        float4 d;
+        d.x = p.dy_perm[perm_index(p, i + 0)];
+        d.y = p.dy_perm[perm_index(p, i + 1)];
+        d.z = p.dy_perm[perm_index(p, i + 2)];
+        d.w = p.dy_perm[perm_index(p, i + 3)];
+        p.dp_out[i + 0] = d.x;
+        p.dp_out[i + 1] = d.y;
+        p.dp_out[i + 2] = d.z;
+        p.dp_out[i + 3] = d.w;
+        return d;
+    }
+    __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float dy, Acc& acc) {
         float q, o;
         fq_core(x, c, q, o);
+        if constexpr (PERM) {
+            if (p.dy_perm) dy = gather1(p, i);
+        }
         nq_accumulate(q, o, dy, p.lam, p.tmode, acc);
         return 0.f;
     }
     static constexpr bool kVec4 = true;
-    __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t, const float4& x, const float4& dy, Acc& acc) {
+    __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t i, const float4& x, const float4& dy, Acc& acc) {
         float4 q, o;
         fq_core4(x, c, q, o);
-        nq_accumulate4(q, o, dy, c, p.lam, p.tmode, acc);
+        nq_accumulate4(q, o, (PERM && p.dy_perm) ? gather4(p, i) : dy, c, p.lam, p.tmode, acc);
         return o;
     }
     static constexpr bool kVec4c = true;
-    __device__ static __forceinline__ float4 elem4c(const Params& p, const Ctx* c, int64_t, const float4& x, const float4& dy, Acc* acc) {
+    __device__ static __forceinline__ float4 elem4c(const Params& p, const Ctx* c, int64_t i, const float4& x, const float4& dy, Acc* acc) {
         float4 q, o;
         fq_core4c(x, c, q, o);
-        nq_accumulate4c(q, o, dy, c, p.lam, p.tmode, acc);
+        nq_accumulate4c(q, o, (PERM && p.dy_perm) ? gather4(p, i) : dy, c, p.lam, p.tmode, acc);
         return o;
     }
 };
+template <>
+struct OpT<OP_BWD> : BwdOp<false> {};
+template <>
+struct OpT<OP_BWD_PERM> : BwdOp<true> {};
 
 template <>
 struct OpT<OP_FUSED> : OpBase {

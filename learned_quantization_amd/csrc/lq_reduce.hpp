@@ -48,7 +48,7 @@ __device__ __forceinline__ void emit_direct(const Params& p, int64_t g, const Ac
 // partial (then idx is the group index) -- the finished outputs.
 template <int OP>
 __device__ __forceinline__ void write_partial_t(const Params& p, int64_t idx, const Acc& acc) {
-    if constexpr (OP == OP_BWD || OP == OP_FUSED) {
+    if constexpr (OP == OP_BWD || OP == OP_FUSED || OP == OP_BWD_PERM) {
         if (p.direct) {
             emit_direct<OP>(p, idx, acc);
             return;

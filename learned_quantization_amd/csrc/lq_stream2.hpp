@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
 //  multiple of C) blocks of 256 threads; thread tid sees vectors tid, tid + T, ...; one partial per (block, column).
 // ------------------------------------------------------------------------------------------
 template <int OP, int NT, int U, int BS = kBlock>
-__global__ __launch_bounds__(BS) void k_col_periodic_pipe(Params p, int C, int64_t nblk) {
+__global__ __launch_bounds__(BS, (U <= 2 ? 4 : 0)) void k_col_periodic_pipe(Params p, int C, int64_t nblk) {
     using O = OpT<OP>;
     __shared__ Acc lds[O::kReduce ? BS * 5 : 1];
     const int64_t blk = blockIdx.x;

@@ -511,6 +511,8 @@ struct FinT<OP_BWD> {
 };
 template <>
 struct FinT<OP_FUSED> : FinT<OP_BWD> {};
+template <>
+struct FinT<OP_BWD_PERM> : FinT<OP_BWD> {};
 
 template <>
 struct FinT<OP_MAXBIN_FWD> {

@@ -312,9 +312,19 @@ class _ConvBase(_HostLayer):
         if not self.built:
             self.build(tuple(inputs.shape), device=inputs.device)
         pre, self._q_pre = getattr(self, "_q_pre", None), None   # set by FakeQuantBatch.quantize_all() (one launch for all)
-        qk = pre[0] if pre is not None else self.nested_q_k_layer(self.kernel)             # NQ-L:340
         x = inputs.permute(0, 3, 1, 2) if self.data_format == "NHWC" else inputs
-        w = qk.permute(3, 2, 0, 1)                                                         # HWIO -> OIHW view
+        nested = self.nested_q_k_layer
+        if pre is not None and len(pre) > 2 and pre[2] is not None:
+            w = pre[2]                                   # the batch emitted the OIHW companion with the same launch
+        elif pre is not None:
+            w = pre[0].permute(3, 2, 0, 1)                                                 # HWIO -> OIHW view
+        elif nested.built and nested.penalty_threshold is not None and self.kernel.is_cuda:
+            # NQ-L:340 with K1 writing the OIHW tensor MIOpen consumes (and K2 reading its OIHW weight gradient): same
+            # values as nested(kernel).permute(3, 2, 0, 1), without the two transposition launches
+            w = ops.my_custom_gradient_oihw(self.kernel, nested.scale, nested.penalty_threshold,
+                                            defer_scale_grad=nested.defer_scale_grad)
+        else:
+            w = nested(self.kernel).permute(3, 2, 0, 1)                                    # NQ-L:340; HWIO -> OIHW view
         if self.padding == "SAME":
             ph = _same_padding(x.shape[-2], self.kernel_size[0], self.strides[0])
             pw = _same_padding(x.shape[-1], self.kernel_size[1], self.strides[1])

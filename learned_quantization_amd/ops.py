@@ -212,6 +212,77 @@ class _NestedQuantFn(torch.autograd.Function):
         return (dy if ctx.needs_input_grad[0] else None), ds, None, None      # :118  dP is dy itself (STE)
 
 
+def _conv_extents(shape):
+    kh, kw, ci, co = (int(d) for d in shape)
+    return kh * kw, ci, co
+
+
+def fq_forward_oihw(kernel: torch.Tensor, scale: torch.Tensor):
+    """K1 on an HWIO conv kernel (custom_layers.py:321, 340) that also emits the OIHW tensor MIOpen consumes: returns
+    (out_hwio, out_oihw) with out_oihw == out_hwio.permute(3, 2, 0, 1) bit for bit, in ONE launch (no transpose kernel)."""
+    lib = _hip.load()
+    p = _hip.require_device_f32(kernel, "kernel")
+    s = _hip.require_device_f32(scale, "scale")
+    if p.dim() != 4:
+        raise ValueError("fq_forward_oihw needs an HWIO conv kernel (kh, kw, ci, co)")
+    hw, ci, co = _conv_extents(p.shape)
+    outer, G, inner = _desc(p, s)
+    out = torch.empty_like(p)
+    out_oihw = torch.empty((co, ci, p.shape[0], p.shape[1]), dtype=torch.float32, device=p.device)
+    _hip.check(lib.lq_fq_forward_oihw(_hip.ptr(p), _hip.ptr(s), _hip.ptr(out), _hip.ptr(out_oihw), hw, ci, co,
+                                      outer, G, inner, _hip.stream_ptr(p.device)), "lq_fq_forward_oihw")
+    return out, out_oihw
+
+
+def fq_scale_grad_oihw(kernel: torch.Tensor, scale: torch.Tensor, dy_oihw: torch.Tensor, penalty_threshold: float):
+    """K2+K3 with the upstream gradient in OIHW order (MIOpen's weight gradient as it stands): returns (ds, dP_hwio);
+    ds is bit-identical to ``fq_scale_grad(kernel, scale, dy_oihw.permute(2, 3, 1, 0))``, dP is that permuted dy."""
+    lib = _hip.load()
+    p = _hip.require_device_f32(kernel, "kernel")
+    s = _hip.require_device_f32(scale, "scale")
+    d = _hip.require_device_f32(dy_oihw, "dy_oihw")
+    hw, ci, co = _conv_extents(p.shape)
+    if tuple(d.shape) != (co, ci, p.shape[0], p.shape[1]):
+        raise ValueError(f"dy_oihw shape {tuple(d.shape)} does not match the kernel {tuple(p.shape)}")
+    outer, G, inner = _desc(p, s)
+    ds = torch.empty_like(s)
+    dP = torch.empty_like(p)
+    ws = _hip.workspace_for(p.device, outer, G, inner)
+    _hip.check(lib.lq_fq_scale_grad_oihw(_hip.ptr(p), _hip.ptr(s), _hip.ptr(d), float(penalty_threshold), _hip.ptr(ds),
+                                         _hip.ptr(dP), _hip.ptr(ws), ws.numel(), hw, ci, co, outer, G, inner,
+                                         _hip.stream_ptr(p.device)), "lq_fq_scale_grad_oihw")
+    return ds, dP
+
+
+class _NestedQuantConvFn(torch.autograd.Function):
+    """The nested-quantization op on an HWIO conv kernel, handing MIOpen its OIHW tensor directly: forward K1 with the OIHW
+    companion store, backward K2+K3 reading MIOpen's OIHW weight gradient and returning dP in HWIO order.  Same q, out and
+    ds as ``_NestedQuantFn`` bit for bit (custom_layers.py:49-120, 338-350); two transposition launches fewer per layer."""
+
+    @staticmethod
+    def forward(ctx, kernel, scale, penalty_threshold, defer_scale_grad=False):
+        ctx.save_for_backward(kernel, scale)
+        ctx.penalty_threshold = float(penalty_threshold)
+        ctx.defer = bool(defer_scale_grad)
+        return fq_forward_oihw(kernel, scale)[1]
+
+    @staticmethod
+    def backward(ctx, dy_oihw):
+        kernel, scale = ctx.saved_tensors
+        if ctx.defer or not ctx.needs_input_grad[1]:
+            return (dy_oihw.permute(2, 3, 1, 0) if ctx.needs_input_grad[0] else None), None, None, None
+        ds, dP = fq_scale_grad_oihw(kernel, scale, dy_oihw, ctx.penalty_threshold)
+        return (dP if ctx.needs_input_grad[0] else None), ds, None, None
+
+
+def my_custom_gradient_oihw(kernel, scale, penalty_threshold, *, defer_scale_grad=False):
+    """``my_custom_gradient`` for an HWIO conv kernel whose consumer wants OIHW: returns the fake-quantised kernel in OIHW
+    layout (co, ci, kh, kw), contiguous.  Gradients flow back to the HWIO parameter."""
+    if isinstance(penalty_threshold, torch.Tensor):
+        penalty_threshold = float(penalty_threshold)
+    return _NestedQuantConvFn.apply(kernel, scale, penalty_threshold, defer_scale_grad)
+
+
 class _STEQuantFn(torch.autograd.Function):
     """CL custom_layers.py:49-64 -- forward K1, backward (dy, zeros_like(scale))."""
 

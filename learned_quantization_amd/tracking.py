@@ -62,14 +62,14 @@ class NestedScaleTrackingCallback:
     # ---- statistics (device side)
     def stats(self):
         """{'unique_k', 'unique_b', 'max_k' (max|q| over axis 1), 'max_b'} -- custom_callbacks.py:84-129."""
-        qk = ops.quantized_integers(self.param.data, self.k_scale.data, torch.float32)
-        qb = ops.quantized_integers(self.layer.b.data, self.b_scale.data, torch.float32)
         axis = 1 if self.param.dim() > 1 else 0
+        b = self.layer.b.data
         return {
             "unique_k": int(ops.q_unique(self.param.data, self.k_scale.data)[0].numel()),
-            "unique_b": int(ops.q_unique(self.layer.b.data, self.b_scale.data)[0].numel()),
+            "unique_b": int(ops.q_unique(b, self.b_scale.data)[0].numel()),
             "max_k": ops.q_absmax_over_axis(self.param.data, self.k_scale.data, axis).flatten().cpu(),
-            "max_b": float(qb.abs().max()),
+            # global max|q| of the bias (custom_callbacks.py:123): the same kernel, the bias viewed as (1, n, 1)
+            "max_b": float(ops.q_absmax_over_axis(b.reshape(1, -1), self.b_scale.data.reshape(1, 1), 1)),
         }
 
     @staticmethod

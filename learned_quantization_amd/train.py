@@ -149,7 +149,10 @@ class Trainer:
 
     def _capture(self, fn):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # with a process group alive its watchdog THREAD polls events while this thread captures: "thread_local" keeps
+        # that legal (the default "global" mode makes every other thread's HIP call an error during the capture)
+        mode = "thread_local" if self.dp is not None else "global"
+        with torch.cuda.graph(g, capture_error_mode=mode):
             out = fn()
         return g, out
 

@@ -129,8 +129,10 @@ def maxbin_term_grads(P, s, c, outer, G, inner):
     return dP, ds, ds_abs
 
 
-def difference_term_grads(P, s, c, outer, G, inner):
-    """d(c * mean |P - P/s|): returns (dP, ds, ds_abs)."""
+def difference_term_grads(P, s, c, outer, G, inner, with_dP_abs=False):
+    """d(c * mean |P - P/s|): returns (dP, ds, ds_abs) [, dP_abs].  dP_i = g_i - g_i/s is itself a sum of TWO signed terms
+    (the gradient through P and the one through P/s, which autodiff adds): they cancel when s is near 1, so its yardstick
+    is |g_i| + |g_i/s|, not |dP_i|."""
     P = np.asarray(P, np.float64).reshape(-1)
     s = np.asarray(s, np.float64).reshape(-1)
     gid = group_ids(outer, G, inner)
@@ -140,6 +142,8 @@ def difference_term_grads(P, s, c, outer, G, inner):
     terms = g * pq / s[gid]
     ds = np.bincount(gid, weights=terms, minlength=G)
     ds_abs = np.bincount(gid, weights=np.abs(terms), minlength=G)
+    if with_dP_abs:
+        return dP, ds, ds_abs, np.abs(g) + np.abs(g / s[gid])
     return dP, ds, ds_abs
 
 
@@ -173,8 +177,8 @@ def penalty_grads(kind, layers, rate):
             e["dK"], e["dsK"], e["dsK_abs"] = maxbin_term_grads(K, sK, cK, *dK)
             e["db"], e["dsb"], e["dsb_abs"] = maxbin_term_grads(b, sb, cb, *db)
         elif kind == "difference":
-            e["dK"], e["dsK"], e["dsK_abs"] = difference_term_grads(K, sK, cK, *dK)
-            e["db"], e["dsb"], e["dsb_abs"] = difference_term_grads(b, sb, cb, *db)
+            e["dK"], e["dsK"], e["dsK_abs"], e["dK_abs"] = difference_term_grads(K, sK, cK, *dK, with_dP_abs=True)
+            e["db"], e["dsb"], e["dsb_abs"], e["db_abs"] = difference_term_grads(b, sb, cb, *db, with_dP_abs=True)
         elif kind == "inverse":
             e["dK"] = e["db"] = None
             e["dsK"], e["dsK_abs"] = inverse_term_grads(sK, cK)

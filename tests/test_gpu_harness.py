@@ -200,3 +200,62 @@ def test_functional_sanity_quantization_emerges_without_accuracy_loss(dev, mnist
     assert results[0.0][0] > 10000 and results[0.0][2] == pytest.approx(lq.SCALE_INIT)     # lambda = 0: scales never move
     assert results[1e-8][0] < 300                                                            # lambda > 0: a few dozen/hundred integers
     assert abs(results[1e-8][1] - results[0.0][1]) < 0.05                                    # same accuracy as the unquantised run
+
+
+@pytest.mark.parametrize("kind", ["maxbin", "difference", "inverse"])
+def test_nq_layer_with_loss_term_scale_gradient_is_the_sum_of_both_pieces(dev, kind, tmp_path):
+    """BASELINE.json configs[3] ("nested quantization + custom_loss_terms penalty").  EXTENSION WITHOUT A REFERENCE CALL SITE:
+    the reference's loss-term variant zeroes the op's scale gradient (CL-L:61-62) and its NQ variant is never trained with an
+    SCCE* loss.  A layer that has penalty_threshold set AND is handed to a loss term gets
+        ds = hand-written NQ gradient (NQ-L:62-118, from the dy the op received) + d(rate * penalty)/ds (CL-F:75-275),
+    which is what TensorFlow's autodiff would add up too.  Checked against the oracle's two pieces."""
+    import learned_quantization_amd as lq
+    from oracle import lq_oracle_f64 as O64
+    lam, rate = 2e-3, 0.25
+    lq.reset_layer_names()
+    layer = lq.CustomDenseLayer(seed=0, units=24, penalty_threshold=lam, orientation="rowwise", initializer=lq.RandomNormal(seed=1),
+                                name="d", regularizer=None, input_shape=40, device=dev, penalty_rate=rate)
+    with torch.no_grad():
+        layer.nested_q_w_layer.scale.uniform_(1e-3, 1e-2)
+        layer.nested_q_b_layer.scale.uniform_(1e-3, 1e-2)
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(16, 40, device=dev, generator=g)
+    wgt = torch.randn(16, 24, device=dev, generator=g) * 1e-3
+    qw = layer.nested_q_w_layer(layer.W)
+    qb = layer.nested_q_b_layer(layer.b)
+    qw.retain_grad()
+    qb.retain_grad()
+    task = ((x @ qw + qb) * wgt).sum()
+    cls = {"maxbin": lq.SCCEMaxBin, "difference": lq.SCCEDifference, "inverse": lq.SCCEInverse}[kind]
+    pen = getattr(cls([layer], rate, str(tmp_path)), f"compute_{kind}_penalty")()
+    (task + rate * pen).backward()
+    W, b = layer.W.detach().cpu().numpy(), layer.b.detach().cpu().numpy()
+    sw, sb = layer.nested_q_w_layer.scale.detach().cpu().numpy(), layer.nested_q_b_layer.scale.detach().cpu().numpy()
+    l64 = [(W, sw, O.group_descriptor(W.shape, sw.shape), b, sb, O.group_descriptor(b.shape, sb.shape))]
+    e = O64.penalty_grads(kind, l64, rate)[0]
+    for nested, P, s, dy, pds, pabs, nm in ((layer.nested_q_w_layer, W, sw, qw.grad, e["dsK"], e["dsK_abs"], "W"),
+                                            (layer.nested_q_b_layer, b, sb, qb.grad, e["dsb"], e["dsb_abs"], "b")):
+        _, nq = O.nq_backward(P, s, lam, dy.cpu().numpy())
+        want = nq.reshape(-1).astype(np.float64) + pds
+        got = nested.scale.grad.cpu().numpy().reshape(-1).astype(np.float64)
+        bound = 1e-5 * np.abs(nq.reshape(-1)) + 1e-5 * pabs + 2.0 ** -23 * np.abs(want)
+        assert np.all(np.abs(got - want) <= bound), f"{kind} {nm}: {np.abs(got - want).max()} vs {bound.min()}"
+        assert np.all(nq <= 0)                               # the NQ piece alone is <= 0 (SURVEY section 4); the sum need not be
+
+
+@pytest.mark.parametrize("kind", ["maxbin", "difference"])
+def test_nqcl_trainer_batched_equals_unbatched(dev, kind, tmp_path):
+    """mode "nqcl" through the Trainer: the batched path (NQ ds from lq_batch_scale_grad, penalty ds ADDED by
+    lq_batch_penalty_grads | LQ_PENALTY_ACCUMULATE_DS) must give the step of the per-tensor autograd path."""
+    from learned_quantization_amd.train import Trainer, synthetic_batch
+    x, y = synthetic_batch("mnist", 32, dev, torch.Generator(device=dev).manual_seed(0))
+    res = []
+    for batched in (False, True):
+        tr = Trainer("mnist", "nqcl", (1e-3, 0.05), "rowwise", kind, device=dev, log_dir=str(tmp_path), batched=batched)
+        tr.model.eval()
+        for _ in range(2):
+            tr.step(x, y)
+        res.append([s.detach().clone() for s in tr.scale_opt.param_groups[0]["params"]])
+    for a, b in zip(*res):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5)
+    assert any(bool((s != O.SCALE_INIT).any()) for s in res[0])

@@ -152,8 +152,8 @@ def test_loss_terms_value_and_gradients(dev, kind, orient):
         assert_within_terms(l.nested_q_k_layer.scale.grad.cpu().numpy(), e["dsK"], e["dsK_abs"], f"{kind} {orient} ds_k")
         assert_within_terms(l.nested_q_b_layer.scale.grad.cpu().numpy(), e["dsb"], e["dsb_abs"], f"{kind} {orient} ds_b")
         if kind == "difference":
-            assert_within_terms(l.kernel.grad.cpu().numpy(), e["dK"], None, f"{kind} {orient} dK")
-            assert_within_terms(l.b.grad.cpu().numpy(), e["db"], None, f"{kind} {orient} db")
+            assert_within_terms(l.kernel.grad.cpu().numpy(), e["dK"], e["dK_abs"], f"{kind} {orient} dK")
+            assert_within_terms(l.b.grad.cpu().numpy(), e["db"], e["db_abs"], f"{kind} {orient} db")
         elif kind == "maxbin":
             np.testing.assert_allclose(l.kernel.grad.cpu().numpy(), k.grad.numpy(), rtol=1e-5, atol=0, err_msg=f"{kind} {orient} dK")
             np.testing.assert_allclose(l.b.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-5, atol=0, err_msg=f"{kind} {orient} db")
@@ -184,14 +184,29 @@ def test_scale_adam_matches_keras_restatement(dev):
     assert np.isnan(got[3]) and c.get_config() == {"min_value": 0.5}
 
 
-def test_callback_statistic_absmax_over_axis(dev):
+@pytest.mark.parametrize("shape,orient,axis", [
+    ((3, 3, 8, 16), "channelwise", 1), ((784, 128), "rowwise", 1), ((784, 128), "columnwise", 1), ((784, 128), "scalar", 0),
+    ((3, 3, 64, 128), "channelwise", 1), ((3, 3, 64, 128), "rowwise", 2), ((7, 7, 3, 64), "columnwise", 1),
+    ((1, 1, 256, 1024), "channelwise", 1), ((3, 3, 512, 512), "channelwise", 1), ((3, 3, 512, 512), "scalar", 3),
+    ((128, 10), "rowwise", 1), ((10,), "scalar", 0), ((5, 70000), "rowwise", 1), ((70000, 5), "columnwise", 0)])
+def test_callback_statistic_absmax_over_axis(dev, shape, orient, axis):
+    """np.max(np.abs(floor(k/s)), axis=1) of custom_callbacks.py:98-99 (and any other axis) -- exact: integer atomics on the
+    bit pattern of |q|.  Covers the LDS-table path, the direct path (post > table), the one-output-per-wave path (post == 1)."""
     import learned_quantization_amd as lq
     rng = np.random.default_rng(0)
-    k = rng.normal(0, 0.05, size=(3, 3, 8, 16)).astype(np.float32)
-    s = rng.uniform(1e-3, 1e-2, size=(1, 1, 8, 1)).astype(np.float32)
-    got = lq.q_absmax_over_axis(torch.tensor(k, device=dev), torch.tensor(s, device=dev), axis=1).cpu().numpy()
-    want = np.max(np.abs(O.quantized_integers(k, s)), axis=1)     # custom_callbacks.py:98
+    k = rng.normal(0, 0.05, size=shape).astype(np.float32)
+    s = rng.uniform(1e-3, 1e-2, size=O.scale_shape(shape, orient)).astype(np.float32)
+    got = lq.q_absmax_over_axis(torch.tensor(k, device=dev), torch.tensor(s, device=dev), axis=axis).cpu().numpy()
+    want = np.max(np.abs(O.quantized_integers(k, s)), axis=axis)     # custom_callbacks.py:98
     np.testing.assert_array_equal(got, want)
+    if len(shape) > 1:       # NaN propagates like np.max; all-zero slices give 0
+        k2 = k.copy()
+        k2[0] = 0.0
+        k2.reshape(-1)[-1] = np.nan
+        got = lq.q_absmax_over_axis(torch.tensor(k2, device=dev), torch.tensor(s, device=dev), axis=axis).cpu().numpy()
+        with np.errstate(all="ignore"):
+            want = np.max(np.abs(O.quantized_integers(k2, s)), axis=axis)
+        np.testing.assert_array_equal(got, want)
 
 
 @pytest.mark.parametrize("shape,orient,smag", [((3, 3, 8, 16), "channelwise", 1e-2), ((784, 128), "rowwise", 1.1920929e-05),

@@ -48,7 +48,10 @@ def _check_case(P, s, dy, lam, dev, name=""):
     # fused single-pass kernel gives the same out (bit-exact) and ds
     out2, ds2 = lq.fq_fwd_bwd_fused(Pt, st, dyt, lam)
     np.testing.assert_array_equal(out2.cpu().numpy(), out_o, err_msg=f"{name}: fused out")
-    np.testing.assert_array_equal(ds2.cpu().numpy(), ds.cpu().numpy(), err_msg=f"{name}: fused ds == unfused ds")
+    # the fused and the split traversal may cut a group into different partials (rows per block by operation): same terms,
+    # another summation order -- both are held to the oracle, and to each other at float32 resolution
+    np.testing.assert_allclose(ds2.cpu().numpy(), ds_o, rtol=RTOL, atol=1e-30, equal_nan=True, err_msg=f"{name}: fused ds")
+    np.testing.assert_allclose(ds2.cpu().numpy(), ds.cpu().numpy(), rtol=2e-6, atol=1e-30, equal_nan=True, err_msg=f"{name}: fused ds vs unfused ds")
 
 
 def test_kat_on_gpu(kat, dev):
@@ -122,6 +125,10 @@ STREAM2_SHAPES = [
     ((70001, 64), "rowwise"),          # 16 lanes per row, ragged last wave
     ((9000, 512), "rowwise"),          # rows of 512: round-1 row-small traversal, flat forward
     ((5, 1000000), "columnwise"),      # G = 1 M groups of one element each (inner = 1, outer = 5): column tile with C = 1 M
+    ((2100001, 2), "columnwise"),      # C = 2: flat one-shot column kernel (k_flat_cols), numel % 4 == 2
+    ((1100000, 2, 2), "columnwise"),   # C = 4 with inner = 2: two groups inside every float4
+    ((1050001, 4), "columnwise"),      # C = 4, inner = 1: scale-float4 flat forward + flat column kernel
+    ((1398101, 3), "columnwise"),      # C = 3 (NHWC RGB), numel % 4 == 3
 ]
 
 

@@ -26,14 +26,15 @@ torch.cuda.set_device(0)
 from learned_quantization_amd.train import Trainer, synthetic_batch  # noqa: E402
 
 STEPS = 4
+ONLY_CAPTURED_COLLECTIVES = len(sys.argv) > 2 and sys.argv[2] == "collectives"
 x, y = synthetic_batch("mnist", 32, dev, torch.Generator(device=dev).manual_seed(0))
 
 
-def run(graph=False, **kw):
+def run(graph=False, steps=STEPS, **kw):
     tr = Trainer("mnist", "nq", 2e-4, "rowwise", None, device=dev, seed=42, graph=graph, **kw)
     tr.model.eval()                                      # no dropout in the dense model anyway; keeps BN-free determinism explicit
     step = tr.step_graphed if graph else tr.step
-    losses = [float(step(x, y).detach()) for _ in range(STEPS)]
+    losses = [float(step(x, y).detach()) for _ in range(steps)]
     torch.cuda.synchronize()
     return tr, losses, {n: p.detach().clone() for n, p in tr.model.named_parameters()}
 
@@ -43,9 +44,10 @@ def diff(a, b):
 
 
 out = {}
-_, ref_losses, ref = run()                               # plain single-process trainer (no DataParallel)
-_, refb_losses, refb = run(batched=True)
-variants = {
+if not ONLY_CAPTURED_COLLECTIVES:
+    _, ref_losses, ref = run()                           # plain single-process trainer (no DataParallel)
+    _, refb_losses, refb = run(batched=True)
+variants = {} if ONLY_CAPTURED_COLLECTIVES else {
     "A_hooks_tiny_buckets": dict(ddp_mode="A", bucket_mb=1e-3, force_collectives=True),
     "A_no_overlap": dict(ddp_mode="A", overlap=False, force_collectives=True),
     "A_batched": dict(ddp_mode="A", batched=True, force_collectives=True),
@@ -60,15 +62,18 @@ for name, kw in variants.items():
     base = refb if kw.get("batched") else ref
     out[name] = {"max_param_diff": diff(params, base), "losses": losses, "buckets": len(tr.dp._ranges)}
 # graphed steps against their eager data-parallel counterparts
-for name, kw in {"graph_split_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True),
-                 "graph_split_B_batched": dict(ddp_mode="B", batched=True, force_collectives=True),
-                 "graph_split_A": dict(ddp_mode="A", force_collectives=True),
-                 "graph_collectives_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True, graph_collectives=True),
-                 "graph_collectives_B_batched": dict(ddp_mode="B", batched=True, force_collectives=True, graph_collectives=True)}.items():
+graphed = {"graph_split_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True),
+           "graph_split_B_batched": dict(ddp_mode="B", batched=True, force_collectives=True),
+           "graph_split_A": dict(ddp_mode="A", force_collectives=True)}
+if ONLY_CAPTURED_COLLECTIVES:      # its own process: a collective that cannot be captured on this stack aborts the process group
+    graphed = {"graph_collectives_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True, graph_collectives=True),
+               "graph_collectives_B_batched": dict(ddp_mode="B", batched=True, force_collectives=True, graph_collectives=True)}
+for name, kw in graphed.items():
     try:
         tr, losses, params = run(graph=True, **kw)
         ek = {k: v for k, v in kw.items() if k != "graph_collectives"}
-        _, el, ep = run(**ek)
+        _, el, ep = run(steps=STEPS + 3, **ek)           # step_graphed runs 3 eager warm-up steps before it captures
+        el = el[3:]
         # the graphed optimizers keep the step counter on the device: same arithmetic, compared at float32 resolution
         rel = max(float(((params[k] - ep[k]).abs() / (ep[k].abs() + 1e-12)).max()) for k in params)
         out[name] = {"max_rel_param_diff_vs_eager": rel, "losses": losses, "eager_losses": el,

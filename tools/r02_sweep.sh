@@ -27,19 +27,14 @@ PY
 }
 C256="150528 256 1"; C6144="6144 6144 1"; IN8="2048 2048 8"; C64="602112 64 1"; C3="12845056 3 1"; R32="1 1048576 32"; R512="1 65536 512"
 for rep in a b; do
-for rb in 32 48 64 74 96 128 147 192 256; do
-  run c256_rb${rb}_$rep $C256 LQ_TUNE_PIPE=28 LQ_TUNE_PIPE_FWD=28 LQ_TUNE_COL_RB=$rb LQ_TUNE_S2=32 || exit 1
-  run c6144_rb${rb}_$rep $C6144 LQ_TUNE_PIPE=28 LQ_TUNE_PIPE_FWD=28 LQ_TUNE_COL_RB=$rb LQ_TUNE_S2=32 || exit 1
-  run in8_rb${rb}_$rep $IN8 LQ_TUNE_PIPE=28 LQ_TUNE_PIPE_FWD=28 LQ_TUNE_COL_RB=$rb || exit 1
+  run c256_$rep $C256 || exit 1
+  run c6144_$rep $C6144 || exit 1
+  run in8_$rep $IN8 || exit 1
+  run c64_$rep $C64 || exit 1
+  run c3_$rep $C3 || exit 1
+  run c3_oldper_$rep $C3 LQ_TUNE_S2=64 || exit 1
+  run r32_$rep $R32 || exit 1
+  run r512_$rep $R512 || exit 1
+  run nchw_$rep 256 3 50176 || exit 1
 done
-done
-run c256_flat4 $C256 || exit 1
-run c6144_flat4 $C6144 || exit 1
-run c64_flat4 $C64 || exit 1
-for per in 11 12 22; do
-  run c64_per$per $C64 LQ_TUNE_PERIODIC=$per LQ_TUNE_S2=32 || exit 1
-  run c3_per$per $C3 LQ_TUNE_PERIODIC=$per || exit 1
-done
-run c3_new $C3 || exit 1
-run nchw_ref 256 3 50176 || exit 1
 echo "sweep done"
