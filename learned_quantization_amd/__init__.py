@@ -15,7 +15,8 @@ from .ops import (difference_term, fq_forward, fq_fwd_bwd_fused, fq_scale_grad, 
 from .optim import KerasAdam, ScaleAdam, apply_constraints, non_scale_parameters, scale_parameters
 from .ddp import DataParallel, GradBucket
 from .batch import BatchedScaleAdam, FakeQuantBatch
-from .models import CIFARCNN, MNISTDense, ResNet18Like, build_model
+from .models import CIFARCNN, MNISTDense, ResNet18Like, ResNet50Like, build_model
+from .data import augment_image, preprocess_for_validation
 from .export import save_compress_parameters
 from .tracking import AccuracyLossTrackingCallBack, NestedScaleTrackingCallback
 

@@ -203,6 +203,7 @@ class _BatchFn(torch.autograd.Function):
         lib = _hip.load()
         _hip.check(lib.lq_batch_forward(batch._handle, _hip.stream_ptr(batch.device)), "lq_batch_forward")
         ctx.batch = batch
+        ctx.set_materialize_grads(False)        # an output nobody consumed arrives as None in backward, not as a zero tensor
         # fresh tensor objects over the static buffers: every HWIO output, then the OIHW companions of the conv kernels
         return tuple(e.out.detach() for e in batch.entries) + tuple(batch.entries[i].out_oihw.detach() for i in batch._oihw_idx)
 

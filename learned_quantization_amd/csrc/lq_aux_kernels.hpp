@@ -48,37 +48,15 @@ __global__ void k_inverse_bwd(const float* s, const float* c_dev, float c_scale,
     ds[g] = (sg == 0.0f) ? 0.0f : -((up / (float)G) / sg) / sg;
 }
 
-// f0..f3 are host-computed factors (python-double arithmetic rounded to fp32, as Keras / torch do):
-//   keras: f0 = 1-b1, f1 = 1-b2, f2 = alpha = lr*sqrt(1-b2^t)/(1-b1^t), f3 = eps
-//   torch: f0 = 1-b1, f1 = 1-b2, f2 = lr/(1-b1^t), f3 = eps, f4 = sqrt(1-b2^t)
-__global__ void k_adam(float* s, const float* ds, float* m, float* v, int64_t n, float f0, float f1, float f2, float f3,
-                       float f4, float min_value, int mode) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float g = ds[i];
-    float mi = m[i], vi = v[i], w = s[i];
-    mi = mi + (g - mi) * f0;
-    vi = vi + (g * g - vi) * f1;
-    if (mode == LQ_ADAM_KERAS) {
-        w = w - (mi * f2) / (sqrtf(vi) + f3);
-    } else {
-        const float denom = sqrtf(vi) / f4 + f3;
-        w = w - f2 * (mi / denom);
-    }
-    w = (w < min_value) ? min_value : w;   // MinValueConstraint: max(w, min_value); NaN stays NaN
-    m[i] = mi;
-    v[i] = vi;
-    s[i] = w;
-}
-
-// Same update, with the 1-based step read from device memory (hipGraph-capturable: nothing about the
-// step is baked into the launch).  Keras mode forms beta^t in fp32 like tf.pow; torch mode in fp64.
+// K6: Adam + MinValueConstraint for one scale tensor.  The 1-based step comes from device memory (hipGraph-capturable: nothing
+// about the step is baked into the launch) or, for eager steps, from `step_host` -- the same device arithmetic either way.
+// Keras mode forms beta^t in fp32 like tf.pow; torch mode in fp64.
 __global__ void k_adam_dev(float* s, const float* ds, float* m, float* v, int64_t n, float lr, float b1, float b2, double lr_d,
-                           double b1_d, double b2_d, float f0, float f1, float eps, const int64_t* step_dev, float min_value,
-                           int mode) {
+                           double b1_d, double b2_d, float f0, float f1, float eps, const int64_t* step_dev, int64_t step_host,
+                           float min_value, int mode) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int64_t step = step_dev[0];
+    const int64_t step = step_dev ? step_dev[0] : step_host;      // one arithmetic for both forms: graphed == eager bit for bit
     const float g = ds[i];
     float mi = m[i], vi = v[i], w = s[i];
     mi = mi + (g - mi) * f0;

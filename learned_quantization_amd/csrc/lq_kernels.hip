@@ -433,10 +433,18 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         static const int tune_u2 = getenv("LQ_TUNE_U2") ? atoi(getenv("LQ_TUNE_U2")) : -1;   // development knob: force 0/1
         const bool want_u2 = tune_u2 >= 0 ? tune_u2 == 1 : (OP == OP_BWD || p.tmode >= 1);
         const bool u2 = (OP == OP_BWD || OP == OP_FUSED) && want_u2 && vec && nt && pl.bs == 512;
+        // rows with a folded tail or with chunks off the 16-byte grid take the TAIL instantiation (see row_stream_body)
+        auto needs_tail = [&](int64_t CH) {
+            const int64_t r = pl.L % CH;
+            return pl.L % 4 != 0 || (pl.L > CH && r != 0 && r * 8 <= CH);
+        };
         if (u2) {
             const int64_t nc2 = row_chunks(pl.L, (int64_t)pl.bs * 8);
             const dim3 grid2 = grid3d ? dim3((unsigned)nc2, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)(pl.R * nc2));
-            hipExtLaunchKernelGGL((k_row_stream<OP, 4, 512, 1, 2>), grid2, dim3(512), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, nc2, grid3d);
+            if (needs_tail((int64_t)pl.bs * 8))
+                hipExtLaunchKernelGGL((k_row_stream<OP, 4, 512, 1, 2, 1>), grid2, dim3(512), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, nc2, grid3d);
+            else
+                hipExtLaunchKernelGGL((k_row_stream<OP, 4, 512, 1, 2, 0>), grid2, dim3(512), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, nc2, grid3d);
             // the finalize that follows must walk the partial layout this launch produced
             pl.CH = pl.bs * 8;
             pl.nc = nc2;
@@ -448,8 +456,10 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         }
         // hipExtLaunchKernelGGL with NULL events is a plain launch; with lq_profile_events() set, the events take the kernel's own
         // begin / end timestamps (what rocprofv3 reports as its duration)
-#define LQ_LAUNCH_STREAM(VEC_, BS_, NT_) \
-        hipExtLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_>), grid, dim3(BS_), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, pl.nc, grid3d)
+        const bool tail1 = needs_tail((int64_t)pl.CH);
+#define LQ_LAUNCH_STREAM(VEC_, BS_, NT_) do { \
+        if (VEC_ == 1 || tail1) hipExtLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_, 1, 1>), grid, dim3(BS_), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, pl.nc, grid3d); \
+        else hipExtLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_, 1, 0>), grid, dim3(BS_), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, pl.nc, grid3d); } while (0)
         if (vec) {
             if (pl.bs == 1024) {
                 if (nt) LQ_LAUNCH_STREAM(4, 1024, 1);
@@ -826,19 +836,13 @@ int lq_scale_adam_step(float* s, const float* ds, float* m, float* v, int64_t n,
     LQ_REQUIRE_PTR(ds);
     LQ_REQUIRE_PTR(m);
     LQ_REQUIRE_PTR(v);
-    const float f0 = (float)(1.0 - beta1), f1 = (float)(1.0 - beta2);
-    float f2, f4 = 1.0f;
-    if (mode == LQ_ADAM_KERAS) {
-        // Keras 2.11: beta powers in fp32 (tf.pow on the cast hyper-parameter), alpha in fp32
-        const float b1p = powf((float)beta1, (float)step), b2p = powf((float)beta2, (float)step);
-        f2 = (float)lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
-    } else {
-        // torch.optim.Adam: bias corrections in python doubles
-        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-        f2 = (float)(lr / bc1);
-        f4 = (float)sqrt(bc2);
-    }
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, s, ds, m, v, n, f0, f1, f2, (float)eps, f4, min_value, mode);
+    // the bias corrections are formed on the device from `step` with the arithmetic of lq_scale_adam_step_dev (Keras 2.11: beta
+    // powers and alpha in fp32, tf.pow on the cast hyper-parameter; torch: python doubles), so that a step replayed from a
+    // hipGraph (device-side counter) and an eager step give the same bits -- the thresholded scale gradient amplifies a
+    // last-bit difference of a scale into visibly different trajectories
+    hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, s, ds, m, v, n,
+                       (float)lr, (float)beta1, (float)beta2, lr, beta1, beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
+                       (float)eps, (const int64_t*)nullptr, step, min_value, mode);
     return check_hip("adam launch");
 }
 
@@ -853,7 +857,7 @@ int lq_scale_adam_step_dev(float* s, const float* ds, float* m, float* v, int64_
     if (!step_dev || !aligned(step_dev, 8)) return fail(LQ_EINVAL, "lq_scale_adam_step_dev: step_dev must be an 8-byte aligned device pointer");
     hipLaunchKernelGGL(k_adam_dev, dim3((unsigned)ceil_div(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, s, ds, m, v, n,
                        (float)lr, (float)beta1, (float)beta2, lr, beta1, beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
-                       (float)eps, step_dev, min_value, mode);
+                       (float)eps, step_dev, (int64_t)0, min_value, mode);
     return check_hip("adam (device step) launch");
 }
 

@@ -35,7 +35,10 @@ __device__ __forceinline__ void store4(float* p, const float4& v) {
     }
 }
 
-template <int OP, int VEC, int BS, int NT, int U = 1>
+// TAIL = 1: rows whose last chunk carries a folded tail, or whose chunks do not start on a 16-byte line (scalar head / tail
+// elements).  Rows without either (the BENCH shape, rows of 2^k elements, ...) run the TAIL = 0 instantiation, which keeps the
+// registers of the round-1 kernel (the hoisted tail loads cost 7-14 VGPRs).
+template <int OP, int VEC, int BS, int NT, int U = 1, int TAIL = 1>
 __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int64_t nc, int64_t row, int64_t ck, int64_t g) {
     using O = OpT<OP>;
     constexpr int CH = BS * 4 * U;
@@ -74,6 +77,28 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
             d[u] = x[u];
             if (O::kDy) d[u] = load4<NT>(p.dy + il);
         }
+        // The folded tail (one more float4 for a few threads of a row's last chunk) and the scalar head / tail elements of rows
+        // that do not start on a 16-byte line are loaded HERE, together with the main loads: as a second and third dependent
+        // load round after the main pass they doubled the lifetime of every last-chunk block (rows of 4100 / 4099 elements:
+        // K1 5.8, K4 5.3 TB/s against 6.3 / 6.0 for rows of 2048)
+        const bool fold = TAIL && len4 > BS * U;          // block-uniform
+        const int je = BS * U + (int)threadIdx.x;
+        float4 xe = make_float4(0.f, 0.f, 0.f, 0.f), de = xe;
+        if (__builtin_expect(fold, 0)) {
+            const int64_t ie0 = vbase + (int64_t)(je < len4 ? je : 0) * 4;
+            xe = load4<NT>(p.P + ie0);
+            de = xe;
+            if (O::kDy) de = load4<NT>(p.dy + ie0);
+        }
+        const int tail = vlen & 3;
+        const int t = (int)threadIdx.x;
+        const bool edge = TAIL && (t < head || (t >= 8 && t - 8 < tail));     // threads 0..head-1 and 8..8+tail-1: at most 6 elements per chunk
+        const int64_t is = t < head ? base + t : vbase + (int64_t)len4 * 4 + (t - 8);
+        float xs = 0.f, dsc = 0.f;
+        if (edge) {
+            xs = p.P[is];
+            if (O::kDy) dsc = p.dy[is];
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the scale fetch + reciprocal below
         const Ctx ctx = O::ctx(p, g);
 #pragma unroll
@@ -92,13 +117,9 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
                 if (O::kStore) store4<NT>(p.out + i[u], r);
             }
         }
-        if (__builtin_expect(len4 > BS * U, 0)) {      // folded tail: fewer than BS*U/8 further float4, one more pass
-            const int j = BS * U + (int)threadIdx.x;
-            if (j < len4) {
-                const int64_t ie = vbase + (int64_t)j * 4;
-                const float4 xe = load4<NT>(p.P + ie);
-                float4 de = xe;
-                if (O::kDy) de = load4<NT>(p.dy + ie);
+        if (__builtin_expect(fold, 0)) {                  // folded tail: fewer than BS*U/8 further float4
+            if (je < len4) {
+                const int64_t ie = vbase + (int64_t)je * 4;
                 float4 r;
                 if constexpr (O::kVec4) {
                     r = O::elem4(p, ctx, ie, xe, de, acc);
@@ -111,13 +132,9 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
                 if (O::kStore) store4<NT>(p.out + ie, r);
             }
         }
-        // scalar head (threads 0..head-1) and tail (threads 8..8+tail-1): at most 6 elements per chunk
-        const int tail = vlen & 3;
-        const int t = (int)threadIdx.x;
-        if (t < head || (t >= 8 && t - 8 < tail)) {
-            const int64_t ie = t < head ? base + t : vbase + (int64_t)len4 * 4 + (t - 8);
-            float r = O::elem(p, ctx, ie, p.P[ie], O::kDy ? p.dy[ie] : 0.f, acc);
-            if (O::kStore) p.out[ie] = r;
+        if (edge) {
+            float r = O::elem(p, ctx, is, xs, dsc, acc);
+            if (O::kStore) p.out[is] = r;
         }
     } else {
         float x[4 * U], d[4 * U];
@@ -152,7 +169,7 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
     }
 }
 
-template <int OP, int VEC, int BS, int NT, int U = 1>
+template <int OP, int VEC, int BS, int NT, int U = 1, int TAIL = 1>
 __global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params p, int64_t L, int64_t nc, int grid3d) {
     int64_t row, ck, g;
     if (grid3d) {
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 8 : 0)) void k_row_stream(Params 
         ck = unit - row * nc;
         g = row % p.G;
     }
-    row_stream_body<OP, VEC, BS, NT, U>(p, L, nc, row, ck, g);
+    row_stream_body<OP, VEC, BS, NT, U, TAIL>(p, L, nc, row, ck, g);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -140,6 +140,10 @@ class CustomQuantizedScaleLayer(nn.Module):
         self.scale = nn.Parameter(torch.full(shape, SCALE_INIT, dtype=torch.float32, device=device))  # NQ-L:156
         self.scale.lq_constraint = self.constraint                 # found by optim.apply_constraints
         self.scale.lq_is_scale = True
+        if self.penalty_rate is not None and not hasattr(self, "penalty_rate_weight"):
+            # the MNIST loss-term variant keeps the rate as a NON-trainable weight of the nested layer
+            # (MNIST/custom_loss_terms/custom_components/custom_layers.py:97-102): a buffer here, saved with the model
+            self.register_buffer("penalty_rate_weight", torch.tensor(float(self.penalty_rate), dtype=torch.float32, device=device))
         self.scale_name = self._SCALE_NAMES[self.orientation]
         self.built = True
 

@@ -75,8 +75,9 @@ for name, kw in graphed.items():
         _, el, ep = run(steps=STEPS + 3, **ek)           # step_graphed runs 3 eager warm-up steps before it captures
         el = el[3:]
         # the graphed optimizers keep the step counter on the device: same arithmetic, compared at float32 resolution
-        rel = max(float(((params[k] - ep[k]).abs() / (ep[k].abs() + 1e-12)).max()) for k in params)
-        out[name] = {"max_rel_param_diff_vs_eager": rel, "losses": losses, "eager_losses": el,
+        rels = {k: float((params[k] - ep[k]).abs().max() / ep[k].abs().max()) for k in params}     # per tensor, against its magnitude
+        worst = max(rels, key=rels.get)
+        out[name] = {"max_rel_param_diff_vs_eager": rels[worst], "worst_tensor": worst, "losses": losses, "eager_losses": el,
                      "graphs": 1 + (tr.graph_update is not None)}
     except Exception as e:                               # reported, judged by the test
         out[name] = {"error": repr(e)[:300]}

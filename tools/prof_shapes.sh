@@ -6,8 +6,9 @@
 out=$1; shift
 cases=("$@")
 if [ ${#cases[@]} -eq 0 ]; then
-  cases=("nhwc_c256:150528,256,1" "nhwc_c64:602112,64,1" "nhwc_c3:12845056,3,1" "col_6144:6144,6144,1" "inner8:2048,2048,8"
-         "rows_1m_x32:1,1048576,32" "rows_64k_x512:1,65536,512" "bench_nchw:256,3,50176")
+  cases=("bench_nchw:256,3,50176" "per_tensor_flat:1,1,38535168" "rows_16k_x2048:1,16384,2048" "hwio_3x3x2048x2048:9,2048,2048"
+         "rows_8k_x4100:1,8192,4100" "rows_8k_x4099:1,8192,4099" "rows_64k_x512:1,65536,512" "rows_1m_x32:1,1048576,32"
+         "nhwc_c3:12845056,3,1" "nhwc_c64:602112,64,1" "nhwc_c256:150528,256,1" "col_6144:6144,6144,1" "inner8:2048,2048,8")
 fi
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
@@ -21,3 +22,4 @@ for c in "${cases[@]}"; do
   echo "profiled $name"
 done
 python3 tools/prof_shapes_summary.py $out "${cases[@]}" > $out/summary.json && echo "summary written"
+python3 tools/prof_shapes_summary.py --table $out/summary.json > $out/table.md && cat $out/table.md

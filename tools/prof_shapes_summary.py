@@ -9,6 +9,26 @@ import json
 import os
 import sys
 
+if sys.argv[1] == "--table":
+    # markdown table of a summary.json: one row per descriptor, K1 / K2 / K4 traversal kernel, rocprofv3 average duration ->
+    # algorithmic GB/s and fraction of the 8 TB/s HBM peak, HBM traffic over algorithmic bytes from the PMC passes
+    d = json.load(open(sys.argv[2]))
+    print("| descriptor (outer, G, inner) | K1 kernel | K1 GB/s (frac) | K2 kernel | K2 GB/s (frac) | K4 kernel | K4 GB/s (frac) | HBM traffic / algorithmic (K1, K2, K4) |")
+    print("|---|---|---|---|---|---|---|---|")
+    for name, e in d.items():
+        cells, traf = [], []
+        for op in ("0", "1", "2"):
+            ks = [(k, v) for k, v in e["kernels"].items() if "finalize" not in k and "<" in k and k.split("<")[1].split(",")[0].split(">")[0].strip() == op]
+            if not ks:
+                cells += ["-", "-"]
+                traf.append("-")
+                continue
+            k, v = max(ks, key=lambda kv: kv[1].get("avg_us", 0))
+            cells += [f"`{k.replace('lq::', '')}`", f"{v.get('algorithmic_GBs', 0):.0f} ({v.get('frac_of_8TBs', 0):.2f})"]
+            traf.append(f"{v['traffic_over_algorithmic']:.3f}" if "traffic_over_algorithmic" in v else "-")
+        print(f"| {name} {tuple(e['descriptor'])} | " + " | ".join(cells) + " | " + ", ".join(traf) + " |")
+    sys.exit(0)
+
 out = sys.argv[1]
 cases = sys.argv[2:]
 ALGO = {"0": 8, "1": 8, "2": 12}      # bytes per element by OP template argument: K1 fwd, K2 bwd, K4 fused
