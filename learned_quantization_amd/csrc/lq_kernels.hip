@@ -75,6 +75,8 @@ struct Plan {
 
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+static bool flat_cols_ok(int64_t C) { return C == 8 || C == 16 || C == 32 || C == 64; }
+
 // Chunks of CH elements per row of length L.  A tail of at most CH/8 elements is folded into the previous chunk (the
 // traversal's last chunk takes whatever remains) instead of getting a block of its own.
 static int64_t row_chunks(int64_t L, int64_t CH) {
@@ -141,6 +143,12 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
                 pl.ysplit = nby;
                 pl.per4 = per4;
                 pl.np = nby * C;
+                // the one-shot flat column kernel (lq_stream2.hpp k_flat_cols: C <= 4 or C = 8, 16, 32, 64 at streaming sizes)
+                // writes one partial per (block of 1024 float4, column): size the workspace for it
+                if (per4 && flat_cols_ok(C)) {
+                    const int64_t fb = ceil_div(ceil_div(outer * C, 4) + 1, (int64_t)kFlatColsBlock * 2);
+                    if (fb * C > pl.np) pl.np = fb * C;
+                }
                 pl.gstride = inner;
                 pl.n1 = nby;
                 pl.stride1 = C;
@@ -298,7 +306,8 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     if constexpr (OP == OP_FWD) {
         const bool one_group = p.inner % 4 == 0;                                             // a float4 never straddles groups
         const bool scale4 = p.inner == 1 && p.G % 4 == 0 && aligned(p.s, 16) && !(off & 32);   // its 4 scales are one float4
-        if (!(off & 1) && (one_group || scale4)) {
+        const bool cols_pow2 = pl.mode == MODE_COL && pl.per4 && flat_cols_ok(pl.C) && !(off & 64);   // k_flat_cols below: 1-2 % faster
+        if (!(off & 1) && (one_group || scale4) && !cols_pow2) {
             const int64_t nv = n >> 2;
             const int64_t blocks = ceil_div(nv, 512);
             if (blocks <= 2147483647ll) {
@@ -324,6 +333,22 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     }
     if (pl.mode == MODE_COL) {
         constexpr int kUp = (OP == OP_FWD) ? 4 : 2;            // float4 per stream in flight: one stream wants 4, two streams 2
+        if (pl.C <= 64 && pl.per4 && flat_cols_ok(pl.C) && !(off & 64) && OP != OP_BWD) {
+            // C = 8, 16, 32, 64 as a flat one-shot stream: K1 and K4 (the read-only K2 is faster in the periodic form)
+            const int64_t nv = n >> 2;                        // numel = outer * C is a multiple of 8
+            constexpr int kU = 2;
+            const int64_t fb = ceil_div(nv, (int64_t)kFlatColsBlock * kU);
+            if (fb <= 2147483647ll && (OP == OP_FWD || fb * pl.C <= pl.np)) {
+                if (OP != OP_FWD) {
+                    pl.ysplit = fb;           // the finalize that follows must walk the partial layout this launch produces
+                    pl.np = fb * pl.C;
+                    pl.n1 = fb;
+                }
+                if (nt) hipLaunchKernelGGL((k_flat_cols<OP, 1, kU>), dim3((unsigned)fb), dim3(kFlatColsBlock), 0, st, p, (int)pl.C, nv);
+                else hipLaunchKernelGGL((k_flat_cols<OP, 0, kU>), dim3((unsigned)fb), dim3(kFlatColsBlock), 0, st, p, (int)pl.C, nv);
+                return check_hip("flat column launch") ? -1 : 1;
+            }
+        }
         if (pl.C <= 64) {
             if ((off & 4) || !pl.per4) return 0;
             static const int per = tune_int("LQ_TUNE_PERIODIC", 0);      // development knob: U*10 + (block size / 256)
@@ -429,7 +454,8 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         // BENCH step, and 105 vs 116 us at lambda = 1e-3 where every element takes the exact-ratio + tanh branch; it
         // also halves the partials the finalize walks); the fused kernel only when lambda >= 4e-4 (77.4 vs 81.7 us
         // there, but 77.7 vs 75.4 us at small lambda).  The unit doubles, so the chunk count halves; the workspace
-        // bound (computed for one float4 per thread) still holds.
+        // bound (computed for one float4 per thread) still holds.  Four float4 per thread in K2 were measured in round 2:
+        // 49.5 against 48.0 us on the BENCH tensor -- not better.
         static const int tune_u2 = getenv("LQ_TUNE_U2") ? atoi(getenv("LQ_TUNE_U2")) : -1;   // development knob: force 0/1
         const bool want_u2 = tune_u2 >= 0 ? tune_u2 == 1 : (OP == OP_BWD || p.tmode >= 1);
         const bool u2 = (OP == OP_BWD || OP == OP_FUSED) && want_u2 && vec && nt && pl.bs == 512;

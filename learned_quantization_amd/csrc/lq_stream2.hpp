@@ -292,6 +292,84 @@ __global__ __launch_bounds__(BS, (U <= 2 ? 4 : 0)) void k_col_periodic_pipe(Para
 }
 
 // ------------------------------------------------------------------------------------------
+//  C = 8, 16, 32, 64 columns as a flat ONE-SHOT stream (power-of-two channel counts of NHWC activations).  The looping periodic
+//  form keeps a wave alive through 5-9 dependent load rounds; here, as in the row-stream kernel, a thread owns U float4 of each
+//  stream, issued together, and the block ends after ONE barrier: a lane's four columns are the same in every vector it owns
+//  ((4*512) % C == 0) and the lanes of a wave that share them are C/4 apart, so an xor-shuffle tree over the upper lane bits
+//  leaves the wave totals in lanes 0 .. C/4-1 (fixed order: run-to-run bit-stable); one LDS hop across the block's 8 waves,
+//  merged in wave order by the first C threads: one partial per (block, column).
+//  Measured (profiles/r02/tuning_flat_cols.txt): K4 5.8-6.1 TB/s against 5.4-5.8 for the periodic form, K1 6.2-6.3 against
+//  6.1-6.2 for the scale-float4 flat form; the read-only K2 is SLOWER this way (4.3-5.4 against 5.6-5.9: nothing hides the
+//  shuffle tree and the barrier at the end of so short a wave) and keeps the periodic form, as does every other C <= 64 (a
+//  per-column select + wave-reduction variant for C <= 4 ran at 1.2-2.2 TB/s).
+// ------------------------------------------------------------------------------------------
+constexpr int kFlatColsBlock = 512;
+
+template <int OP, int NT, int U>
+__global__ __launch_bounds__(kFlatColsBlock) void k_flat_cols(Params p, int C, int64_t nv) {
+    using O = OpT<OP>;
+    constexpr int BS = kFlatColsBlock, NW = BS / 64;
+    __shared__ Acc part[O::kReduce ? NW * 64 : 1];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t v0 = (int64_t)blockIdx.x * (BS * U) + threadIdx.x;
+    float4 x[U], d[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t v = v0 + (int64_t)u * BS;
+        valid[u] = v < nv;
+        const int64_t i = (valid[u] ? v : nv - 1) * 4;        // clamp: the loads stay unconditional (nv >= 1 at streaming sizes)
+        x[u] = load4<NT>(p.P + i);
+        d[u] = x[u];
+        if (O::kDy) d[u] = load4<NT>(p.dy + i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t uC = (uint32_t)C;
+    const uint32_t cblk = (uint32_t)(((int64_t)blockIdx.x * (BS * U) * 4) % C);      // block-uniform
+    const uint32_t c0 = (cblk + (uint32_t)threadIdx.x * 4u) & (uC - 1u);             // four fixed, consecutive columns per lane
+    Ctx ctx[4];
+    Acc acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ctx[k] = O::ctx(p, (int64_t)(c0 + (uint32_t)k) / p.inner);
+        acc[k] = O::template init<Acc>();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = (v0 + (int64_t)u * BS) * 4;
+        if (valid[u]) {
+            const float4 o = O::elem4c(p, ctx, i, x[u], d[u], acc);
+            if (O::kStore) store4<NT>(p.out + i, o);
+        }
+    }
+    if (O::kReduce) {
+        const int period = C >> 2;                    // lanes l and l + period share their columns
+        for (int off = 32; off >= period; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Acc o;
+                o.a = __shfl_xor(acc[k].a, off, 64);
+                o.b = __shfl_xor(acc[k].b, off, 64);
+                o.c = __shfl_xor(acc[k].c, off, 64);
+                O::merge(acc[k], o);
+            }
+        }
+        if (lane < period) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) part[wv * 64 + (int)((c0 + (uint32_t)k) & (uC - 1u))] = acc[k];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            Acc r = part[threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) O::merge(r, part[w * 64 + (int)threadIdx.x]);      // fixed wave order
+            write_partial_t<OP>(p, (int64_t)blockIdx.x * C + threadIdx.x, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 //  Tiny rows (L <= 64, L % 4 == 0, 16-B aligned bases): a team of lpr = 2^lg <= 16 lanes owns a row (one float4 per
 //  lane), a wave takes U passes of 64/lpr consecutive rows with every load issued up front, reduces the U teams'
 //  accumulators with DPP (every lane of a team ends with the team total), and then lane (team, u), u < U <= lpr,

@@ -28,7 +28,7 @@ def _data(dev):
     return x, y
 
 
-def _worker(rank, world, port, mode, batched, out_dir):
+def _worker(rank, world, port, mode, batched, out_dir, graph=False, steps=2):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -36,10 +36,12 @@ def _worker(rank, world, port, mode, batched, out_dir):
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")
     from learned_quantization_amd.train import Trainer
-    tr = Trainer("mnist", "nq", 2e-4, "rowwise", None, device=dev, ddp_mode=mode, batched=batched, seed=42 + 7 * rank)
+    tr = Trainer("mnist", "nq", 2e-4, "rowwise", None, device=dev, ddp_mode=mode, batched=batched, seed=42 + 7 * rank, graph=graph)
     x, y = _data(dev)
     xs, ys = x[rank * 8:(rank + 1) * 8], y[rank * 8:(rank + 1) * 8]
-    losses = [float(tr.step(xs, ys).detach()) for _ in range(2)]
+    step = tr.step_graphed if graph else tr.step
+    losses = [float(step(xs, ys).detach()) for _ in range(steps)]
+    torch.cuda.synchronize()
     res = {n: p.detach().cpu().clone() for n, p in tr.model.named_parameters()}
     res["losses"] = losses
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
@@ -66,6 +68,23 @@ def test_two_rank_training_on_one_gpu(tmp_path, mode, batched):
             tr.step(x, y)
         for n, p in tr.model.named_parameters():
             np.testing.assert_allclose(r0[n].numpy(), p.detach().cpu().numpy(), rtol=2e-5, atol=1e-9, err_msg=n)
+
+
+@pytest.mark.parametrize("mode", ["A", "B"])
+def test_two_rank_graphed_step_equals_eager(tmp_path, mode):
+    """world_size 2 (gloo transport, both ranks on the one GPU): graph(backward) -> eager bucketed all-reduce -> graph(update)
+    gives the parameters of the eager data-parallel step, bit for bit, on both ranks."""
+    runs = {}
+    for tag, graph, steps in (("eager", False, 5), ("graph", True, 2)):        # step_graphed: 3 eager warm-up steps, then replays
+        d = tmp_path / tag
+        d.mkdir()
+        mp.spawn(_worker, args=(2, _free_port(), mode, True, str(d), graph, steps), nprocs=2, join=True)
+        runs[tag] = (torch.load(d / "r0.pt"), torch.load(d / "r1.pt"))
+    for k in runs["eager"][0]:
+        if k == "losses":
+            continue
+        assert torch.equal(runs["graph"][0][k], runs["graph"][1][k]), f"graphed replicas diverged at {k}"
+        assert torch.equal(runs["graph"][0][k], runs["eager"][0][k]), f"graphed != eager at {k} (mode {mode})"
 
 
 def _run_script(args, timeout=600):

@@ -248,3 +248,62 @@ def test_int32_view_saturates(dev):
     q = lq.quantized_integers(_t(P, dev), _t(s, dev), torch.int32).cpu().numpy()
     i32 = np.iinfo(np.int32)
     np.testing.assert_array_equal(q, np.array([i32.max, i32.min, 2147483520, i32.max, i32.min, i32.min, 0, i32.max, i32.min, 5], np.int64).astype(np.int32))
+
+
+def _rand_streaming_case(rng):
+    """Random descriptor of 4.2-6 M elements that lands in one of the streaming-size forms (csrc/lq_stream2.hpp): column tile
+    (any C % 4 == 0 > 64, ragged row counts), periodic columns (C <= 64, any C), tiny rows (L in 8..64, L % 4 == 0), rows of
+    68..1020 (flat forward), ragged long rows (TAIL instantiation of the row stream)."""
+    kind = int(rng.integers(0, 5))
+    n = int(rng.integers(4_200_000, 6_000_000))
+    if kind == 0:                                   # column tile
+        inner = int(rng.choice([1, 1, 2, 4, 6, 8, 12]))
+        G = int(rng.integers(17, 700)) * 4 // (4 if inner % 4 == 0 else 1)
+        G = max(G, 68 // inner + 1)
+        while (G * inner) % 4 != 0:
+            G += 1
+        outer = max(n // (G * inner), 2)
+        return (outer, G, inner), "columnwise"
+    if kind == 1:                                   # periodic columns
+        C = int(rng.integers(2, 65))
+        inner = int(rng.choice([d for d in (1, 2, 3, 4, 8) if C % d == 0 and C // d >= 2] or [1]))
+        return (max(n // C, 2), C // inner, inner), "columnwise"
+    if kind == 2:                                   # tiny rows
+        L = int(rng.choice([8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64]))
+        if rng.integers(0, 2):
+            return (n // L, L), "rowwise"
+        outer = int(rng.integers(2, 6))
+        return (outer, n // (L * outer), L), "columnwise"
+    if kind == 3:                                   # rows of 68..1020 elements
+        L = int(rng.integers(17, 256)) * 4
+        return (n // L, L), "rowwise"
+    L = int(rng.integers(1025, 9000))               # long ragged rows
+    return (n // L, L), "rowwise"
+
+
+def test_fuzz_streaming_size_forms(dev):
+    """Seeded random descriptors at streaming size through K1, K2+K3 and K4 against the oracle (bit-exact q / out / max|q|,
+    ds within 1e-5): the round-2 kernels with random ragged extents, scale magnitudes and thresholds."""
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(424242 + SEED_SHIFT)
+    for it in range(10 * ITER_SCALE):
+        shape, orient = _rand_streaming_case(rng)
+        mag = float(10.0 ** rng.uniform(-2, 1))
+        P = rng.normal(0, mag, size=shape).astype(np.float32)
+        s = (rng.uniform(0.5, 2.0, size=O.scale_shape(shape, orient)) * mag * float(10.0 ** rng.uniform(-4, 0))).astype(np.float32)
+        dy = (rng.normal(0, 1, size=shape) * 10.0 ** rng.uniform(-9, -1, size=shape)).astype(np.float32)
+        lam = float(rng.choice([0.0, 1e-11, 1e-6, 1e-3, 3e-2, 0.4]))
+        tag = f"case {it}: shape={shape} orient={orient} lam={lam}"
+        with np.errstate(all="ignore"):
+            q_o, out_o = O.fq_forward(P, s)
+            _, ds_o, im = O.nq_backward(P, s, lam, dy, return_intermediates=True)
+        Pt, st, dt = _t(P, dev), _t(s, dev), _t(dy, dev)
+        out, q = lq.fq_forward(Pt, st, q_dtype=torch.float32)
+        np.testing.assert_array_equal(q.cpu().numpy(), q_o, err_msg=tag)
+        np.testing.assert_array_equal(out.cpu().numpy(), out_o, err_msg=tag)
+        ds, parts = lq.fq_scale_grad(Pt, st, dt, lam, return_parts=True)
+        np.testing.assert_array_equal(parts[0].cpu().numpy(), np.asarray(im["maxvalue"], np.float32).reshape(-1), err_msg=tag)
+        np.testing.assert_allclose(ds.cpu().numpy(), ds_o, rtol=RTOL, atol=1e-30, equal_nan=True, err_msg=tag)
+        out2, ds2 = lq.fq_fwd_bwd_fused(Pt, st, dt, lam)
+        np.testing.assert_array_equal(out2.cpu().numpy(), out_o, err_msg=tag)
+        np.testing.assert_allclose(ds2.cpu().numpy(), ds_o, rtol=RTOL, atol=1e-30, equal_nan=True, err_msg=tag)

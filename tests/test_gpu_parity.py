@@ -125,10 +125,15 @@ STREAM2_SHAPES = [
     ((70001, 64), "rowwise"),          # 16 lanes per row, ragged last wave
     ((9000, 512), "rowwise"),          # rows of 512: round-1 row-small traversal, flat forward
     ((5, 1000000), "columnwise"),      # G = 1 M groups of one element each (inner = 1, outer = 5): column tile with C = 1 M
-    ((2100001, 2), "columnwise"),      # C = 2: periodic columns, numel % 4 == 2
+    ((2100001, 2), "columnwise"),      # C = 2: one-shot flat column kernel (per-column wave reductions), numel % 4 == 2
     ((1100000, 2, 2), "columnwise"),   # C = 4 with inner = 2: two groups inside every float4
-    ((1050001, 4), "columnwise"),      # C = 4, inner = 1: scale-float4 flat forward + periodic columns
+    ((1050001, 4), "columnwise"),      # C = 4, inner = 1: scale-float4 flat forward + flat column kernel
     ((1398101, 3), "columnwise"),      # C = 3 (NHWC RGB), numel % 4 == 3
+    ((600001, 8), "columnwise"),       # C = 8: one-shot flat column kernel, shuffle tree over 5 lane bits
+    ((300000, 16), "columnwise"),      # C = 16
+    ((150001, 32), "columnwise"),      # C = 32
+    ((70001, 64), "columnwise"),       # C = 64: shuffle tree over 2 lane bits
+    ((33001, 16, 4), "columnwise"),    # C = 64 with inner = 4 (16 groups)
     ((1100, 4100), "rowwise"),         # row stream, 4-element tail folded into the last chunk (loads hoisted: TAIL instantiation)
     ((1100, 4099), "rowwise"),         # row stream, chunks off the 16-byte grid: scalar head / tail elements
     ((3, 1500001), "rowwise"),         # long ragged rows, many chunks

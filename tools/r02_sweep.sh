@@ -26,15 +26,15 @@ for r in csv.DictReader(open(f)):
 PY
 }
 C256="150528 256 1"; C6144="6144 6144 1"; IN8="2048 2048 8"; C64="602112 64 1"; C3="12845056 3 1"; R32="1 1048576 32"; R512="1 65536 512"
+C16="2408448 16 1"; C32="1204224 32 1"; C8="4816896 8 1"
 for rep in a b; do
-  run c256_$rep $C256 || exit 1
-  run c6144_$rep $C6144 || exit 1
-  run in8_$rep $IN8 || exit 1
   run c64_$rep $C64 || exit 1
+  run c16_$rep $C16 || exit 1
+  run c8_$rep $C8 || exit 1
   run c3_$rep $C3 || exit 1
-  run c3_oldper_$rep $C3 LQ_TUNE_S2=64 || exit 1
-  run r32_$rep $R32 || exit 1
-  run r512_$rep $R512 || exit 1
   run nchw_$rep 256 3 50176 || exit 1
+  run nchw_u4_$rep 256 3 50176 LQ_TUNE_U4=1 || exit 1
+  run hwio_u4_$rep 9 2048 2048 LQ_TUNE_U4=1 || exit 1
+  run hwio_$rep 9 2048 2048 || exit 1
 done
 echo "sweep done"
