@@ -6,6 +6,7 @@
 //   lq_ops.hpp          per-operation traits (K1 fwd, K2 bwd, K4 fused, K5 penalties, integer view)
 //   lq_reduce.hpp       wave/block reductions (DPP for the standard accumulator, shuffles for custom merges)
 //   lq_traverse.hpp     traversal modes (row stream / row small / column) + finalize kernels
+//   lq_stream2.hpp      streaming-size forms of the column and tiny-row modes (round 2): flat K1, pipelined column tile, ...
 //   lq_aux_kernels.hpp  scale-sized kernels (K5c, K6), integer statistics, device self-test
 //   lq_batch.hpp        device side of the multi-tensor batch
 //   this file           host side: traversal plan, launchers, the extern "C" entry points

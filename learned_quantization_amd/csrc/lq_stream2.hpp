@@ -1,6 +1,6 @@
 // lq_stream2.hpp -- streaming-size (>= 4 M elements) forms of the column and tiny-row traversals (round 2)
 //
-// What rocprofv3 showed for the round-1 kernels of these modes (profiles/r02/shapes_baseline.json; MI355X):
+// What rocprofv3 showed for the round-1 kernels of these modes (profiles/r02/shapes_baseline_counters.json; MI355X):
 //   * every kernel moves exactly its algorithmic bytes (traffic / algorithmic <= 1.03): nothing is re-read;
 //   * the read-only K2 tile already streams at 5.6-5.7 TB/s, but the SAME loop with stores in it (K1: 5.0, K4: 4.9 TB/s)
 //     is a fifth slower.  On gfx9-family hardware loads and stores share one in-order counter (vmcnt): a wave that
@@ -14,6 +14,8 @@
 //   k_col_pipe        column tile with a software pipeline: the loads of iteration i+1 are issued BEFORE the stores of
 //                     iteration i, so the vmcnt wait that covers them does not include those stores.
 //   k_col_periodic_pipe   the same pipeline for the periodic float4 form (C <= 64).
+//   k_flat_cols       C = 8, 16, 32, 64 as a flat one-shot stream with an xor-shuffle tree over the lanes that share columns
+//                     (K1 and K4; the read-only K2 is faster in the periodic form).
 //   k_row_tiny        rows of <= 64 elements: U passes of rows per wave with all loads up front, DPP team reductions
 //                     (VALU only), ONE emit per wave in which lane (team, u) finishes row (u, team).
 // All of them are used for tensors of >= 4 M elements only (kPeriodic4Min): below that the round-1 bodies run, the same
