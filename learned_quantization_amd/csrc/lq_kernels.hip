@@ -132,7 +132,8 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
                 // streaming sizes with float4 columns: the round-2 pipelined tile (lq_stream2.hpp) picks its rows per block per
                 // operation at launch (kColRbFused / kColRbBwd); the plan carries the smaller one, i.e. the larger partial
                 // count, so the workspace bound holds for both
-                if ((double)outer * (double)C >= (double)kPeriodic4Min && C % 4 == 0) RB = kColRbFused;
+                // (C % 4 != 0: the same tile with dword-aligned float4 access, k_col_pipe<..., UA = 1>)
+                if ((double)outer * (double)C >= (double)kPeriodic4Min) RB = kColRbFused;
             }
             if (RB > outer) RB = outer;
             if (!nby) nby = ceil_div(outer, RB);
@@ -295,8 +296,43 @@ template <int OP>
 static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     using O = OpT<OP>;
     const double numel = (double)p.outer * (double)p.G * (double)p.inner;
-    if (numel < (double)kPeriodic4Min || pl.mode == MODE_ROW_BIG) return 0;
+    if (numel < (double)kPeriodic4Min) return 0;
     if (p.out_perm || p.dy_perm) return 0;
+    FlatIdx fx;              // 32-bit forms only (numel < 2^32); the wide forms divide in 64 bits
+    fx.inner = make_fastdiv((uint32_t)(p.inner < 4294967296ll ? p.inner : 1));
+    fx.G = make_fastdiv((uint32_t)(p.G < 4294967296ll ? p.G : 1));
+    (void)fx;
+    if (pl.mode == MODE_ROW_BIG) {
+        // long rows off the 16-byte grid: K1 as a line-aligned flat stream (lq_stream2.hpp k_flat_fwd, group mode 6 / 7)
+        if constexpr (OP == OP_FWD) {
+            static const int off_rb = tune_int("LQ_TUNE_S2", 0);
+            const int64_t nn = p.outer * p.G * p.inner;
+            if (!(off_rb & 256) && p.G > 1 && pl.L % 32 != 0 && aligned(p.P, 16) && aligned(p.out, 16)) {
+                // rows that are not a whole number of 128-byte lines: one group per float4 when L % 4 == 0 (group mode 0 / 2),
+                // else a float4 may straddle a row end (6 / 7)
+                const int64_t nv = nn >> 2;
+                const int rem = (int)(nn & 3);
+                const int64_t blocks = ceil_div(nv + (rem ? 1 : 0), 512);
+                if (blocks <= 2147483647ll) {
+                    const bool ntb = numel * 4.0 >= (double)kNtBytes;
+                    const bool wide = nn >= 4294967296ll;
+#define LQ_FLATR(NT_, GM_) hipLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, p, fx, nv, rem)
+                    if (pl.L % 4 == 0) {
+                        if (ntb) { if (wide) LQ_FLATR(1, 2); else LQ_FLATR(1, 0); }
+                        else { if (wide) LQ_FLATR(0, 2); else LQ_FLATR(0, 0); }
+                    } else if (off_rb & 512) {
+                        return 0;
+                    } else {
+                        if (ntb) { if (wide) LQ_FLATR(1, 7); else LQ_FLATR(1, 6); }
+                        else { if (wide) LQ_FLATR(0, 7); else LQ_FLATR(0, 6); }
+                    }
+#undef LQ_FLATR
+                    return check_hip("flat forward launch") ? -1 : 1;
+                }
+            }
+        }
+        return 0;
+    }
     const bool al16 = aligned(p.P, 16) && (!O::kDy || aligned(p.dy, 16)) && (!O::kStore || aligned(p.out, 16));
     if (!al16) return 0;
     static const int off = tune_int("LQ_TUNE_S2", 0);
@@ -308,12 +344,27 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         const bool one_group = p.inner % 4 == 0;                                             // a float4 never straddles groups
         const bool scale4 = p.inner == 1 && p.G % 4 == 0 && aligned(p.s, 16) && !(off & 32);   // its 4 scales are one float4
         const bool cols_pow2 = pl.mode == MODE_COL && pl.per4 && flat_cols_ok(pl.C) && !(off & 64);   // k_flat_cols below: 1-2 % faster
+        // rows of 4..1023 elements off the 16-byte grid (row-small mode, L % 4 != 0): a float4 straddles at most one row end
+        const bool straddle = pl.mode == MODE_ROW_SMALL && pl.L >= 4 && pl.L % 4 != 0 && !(off & 256);
+        if (straddle) {
+            const int64_t nv = n >> 2;
+            const int rem = (int)(n & 3);
+            const int64_t blocks = ceil_div(nv + (rem ? 1 : 0), 512);
+            if (blocks <= 2147483647ll) {
+                const bool wide = n >= 4294967296ll;
+#define LQ_FLATS(NT_, GM_) hipLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, p, fx, nv, rem)
+                if (nt) { if (wide) LQ_FLATS(1, 7); else LQ_FLATS(1, 6); }
+                else { if (wide) LQ_FLATS(0, 7); else LQ_FLATS(0, 6); }
+#undef LQ_FLATS
+                return check_hip("flat forward launch") ? -1 : 1;
+            }
+        }
         if (!(off & 1) && (one_group || scale4) && !cols_pow2) {
             const int64_t nv = n >> 2;
             const int64_t blocks = ceil_div(nv, 512);
             if (blocks <= 2147483647ll) {
                 const bool wide = n >= 4294967296ll;
-#define LQ_FLAT(NT_, GM_) hipLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, p, nv, 0)
+#define LQ_FLAT(NT_, GM_) hipLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, p, fx, nv, 0)
                 if (one_group) {
                     if (nt) {
                         if (wide) LQ_FLAT(1, 2); else LQ_FLAT(1, 0);
@@ -375,7 +426,8 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
             else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             return check_hip("periodic column launch") ? -1 : 1;
         }
-        if ((off & 2) || pl.C % 4 != 0) return 0;
+        const bool ua = pl.C % 4 != 0;
+        if ((off & 2) || (ua && (off & 2048))) return 0;
         const int64_t nbx = ceil_div(pl.C, 256);
         {
             // rows per block by operation; never fewer than the plan's (the workspace was sized for the plan's partial count)
@@ -395,7 +447,10 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         static const int pipe_f = tune_int("LQ_TUNE_PIPE_FWD", 28);
         const int pipe = (OP == OP_FWD) ? pipe_f : pipe_r;
 #define LQ_PIPE(NT_, U_, NW_) hipLaunchKernelGGL((k_col_pipe<OP, NT_, U_, NW_>), dim3((unsigned)blocks), dim3(NW_ * 64), 0, st, p, pl.C, pl.rps, nbx)
-        if (nt) {
+        if (ua) {
+            if (nt) hipLaunchKernelGGL((k_col_pipe<OP, 1, 2, 8, 1>), dim3((unsigned)blocks), dim3(512), 0, st, p, pl.C, pl.rps, nbx);
+            else hipLaunchKernelGGL((k_col_pipe<OP, 0, 2, 8, 1>), dim3((unsigned)blocks), dim3(512), 0, st, p, pl.C, pl.rps, nbx);
+        } else if (nt) {
             if (pipe == 14) LQ_PIPE(1, 1, 4); else if (pipe == 44) LQ_PIPE(1, 4, 4); else if (pipe == 28) LQ_PIPE(1, 2, 8);
             else if (pipe == 18) LQ_PIPE(1, 1, 8); else if (pipe == 48) LQ_PIPE(1, 4, 8); else if (pipe == 24) LQ_PIPE(1, 2, 4);
             else LQ_PIPE(1, 2, 8);
@@ -408,7 +463,39 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     if constexpr (OP == OP_FWD) {
         return 0;                                      // row-small forward whose float4s straddle groups: cannot happen (L % 4 == 0 there)
     } else {
-        // MODE_ROW_SMALL, scale-gradient ops: tiny rows
+        // MODE_ROW_SMALL, scale-gradient ops.  Rows off the 16-byte grid (or, development knob 1024, any row of 68..1020
+        // elements): aligned float4 windows (lq_stream2.hpp k_row_win)
+        static const int win_all = tune_int("LQ_TUNE_WIN", 1);      // 0: rows with L % 4 == 0 and L > 64 keep the round-1 row-small kernel
+        if (!(off & 128) && pl.L >= 5 && pl.R < 4294967296ll && (pl.L % 4 != 0 || (win_all && pl.L > 64))) {
+            const int nwin = (int)(pl.L % 4 ? (pl.L + 3 + 3) / 4 : pl.L / 4);     // float4s of the widest window of a row
+            int lg = 1;
+            while ((1 << lg) < nwin && lg < 6) ++lg;
+            const int V = lg == 6 ? (nwin + 63) / 64 : 1;
+            const int U = V == 1 ? 2 : 1;
+            const int64_t rows_per_block = (int64_t)kWavesPerBlock * (64 >> lg) * U;
+            const int64_t blocks = ceil_div(pl.R, rows_per_block);
+            if (blocks <= 2147483647ll && V <= 5) {
+                const FastDiv fG = make_fastdiv((uint32_t)p.G);
+#define LQ_WIN(NT_, LG_, V_, U_) hipLaunchKernelGGL((k_row_win<OP, NT_, LG_, V_, U_>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, fG, pl.R, (int)pl.L, n)
+#define LQ_WIN2(NT_) do { \
+                switch (lg * 8 + V) { \
+                    case 1 * 8 + 1: LQ_WIN(NT_, 1, 1, 2); break; \
+                    case 2 * 8 + 1: LQ_WIN(NT_, 2, 1, 2); break; \
+                    case 3 * 8 + 1: LQ_WIN(NT_, 3, 1, 2); break; \
+                    case 4 * 8 + 1: LQ_WIN(NT_, 4, 1, 2); break; \
+                    case 5 * 8 + 1: LQ_WIN(NT_, 5, 1, 2); break; \
+                    case 6 * 8 + 1: LQ_WIN(NT_, 6, 1, 2); break; \
+                    case 6 * 8 + 2: LQ_WIN(NT_, 6, 2, 1); break; \
+                    case 6 * 8 + 3: LQ_WIN(NT_, 6, 3, 1); break; \
+                    case 6 * 8 + 4: LQ_WIN(NT_, 6, 4, 1); break; \
+                    default: LQ_WIN(NT_, 6, 5, 1); break; \
+                } } while (0)
+                if (nt) LQ_WIN2(1); else LQ_WIN2(0);
+#undef LQ_WIN2
+#undef LQ_WIN
+                return check_hip("row-window launch") ? -1 : 1;
+            }
+        }
         if ((off & 8) || pl.L > 64 || pl.L < 8 || pl.L % 4 != 0) return 0;
         const int lg = row_small_lpr_log2_vec(pl.L);         // 1..4
         static const int tiny_u = tune_int("LQ_TUNE_TINY_U", 2);

@@ -16,6 +16,7 @@
 //   k_col_periodic_pipe   the same pipeline for the periodic float4 form (C <= 64).
 //   k_flat_cols       C = 8, 16, 32, 64 as a flat one-shot stream with an xor-shuffle tree over the lanes that share columns
 //                     (K1 and K4; the read-only K2 is faster in the periodic form).
+//   k_row_win         rows of 5..1023 elements off the 16-byte grid (scale-gradient ops): aligned float4 windows per row.
 //   k_row_tiny        rows of <= 64 elements: U passes of rows per wave with all loads up front, DPP team reductions
 //                     (VALU only), ONE emit per wave in which lane (team, u) finishes row (u, team).
 // All of them are used for tensors of >= 4 M elements only (kPeriodic4Min): below that the round-1 bodies run, the same
@@ -36,15 +37,22 @@ namespace lq {
 //            the quotient is the IEEE `/` itself (correctly rounded, ~11 VALU each): building four reciprocal contexts
 //            per thread costs more than it saves when each is used for a single element
 // ------------------------------------------------------------------------------------------
+//     6 / 7: long rows that do not start on 16-byte lines (row mode with inner % 4 != 0, e.g. rows of 4100 or 4099 elements):
+//            the row-stream kernel would start every block in the middle of a 128-byte line (each 1 KB wave access then touches
+//            9 lines instead of 8: K1 5.4-5.9 TB/s); as a flat stream every access is line-aligned, a float4 has one group
+//            unless it straddles a row end -- checked from the groups of its first and last element (32-bit / 64-bit)
+template <bool WIDE>
+__device__ __forceinline__ int64_t flat_group_w(const Params& p, const FlatIdx& fx, int64_t i) {
+    if (WIDE) return (i / p.inner) % p.G;
+    return (int64_t)fd_mod(fx.G, fd_div(fx.inner, (uint32_t)i));        // exact: see FastDiv
+}
 template <int GM>
-__device__ __forceinline__ int64_t flat_group(const Params& p, int64_t i) {
-    if (GM >= 2) return (i / p.inner) % p.G;
-    const uint32_t q = (uint32_t)i / (uint32_t)p.inner;
-    return (int64_t)(q % (uint32_t)p.G);
+__device__ __forceinline__ int64_t flat_group(const Params& p, const FlatIdx& fx, int64_t i) {
+    return flat_group_w<(GM == 2 || GM == 3 || GM == 5 || GM == 7)>(p, fx, i);
 }
 
 template <int OP, int BS, int NT, int GM>
-__global__ __launch_bounds__(BS) void k_flat_fwd(Params p, int64_t nv, int rem) {
+__global__ __launch_bounds__(BS) void k_flat_fwd(Params p, FlatIdx fx, int64_t nv, int rem) {
     using O = OpT<OP>;
     const int64_t v = (int64_t)blockIdx.x * BS + threadIdx.x;
     if (v < nv) {
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(BS) void k_flat_fwd(Params p, int64_t nv, int rem) 
         Acc none = O::template init<Acc>();
         float4 o;
         if (GM == 4 || GM == 5) {
-            const int64_t c = GM == 4 ? (int64_t)((uint32_t)i % (uint32_t)p.G) : i % p.G;
+            const int64_t c = GM == 4 ? (int64_t)fd_mod(fx.G, (uint32_t)i) : i % p.G;
             const float4 sv = *reinterpret_cast<const float4*>(p.s + c);
             float4 q;
             q.x = floorf(x.x / sv.x); q.y = floorf(x.y / sv.y); q.z = floorf(x.z / sv.z); q.w = floorf(x.w / sv.w);   // custom_layers.py:56-59
@@ -66,14 +74,38 @@ __global__ __launch_bounds__(BS) void k_flat_fwd(Params p, int64_t nv, int rem) 
                 store_q(p.q, p.q_dtype, i + 3, q.w);
             }
         } else if (GM == 0 || GM == 2) {
-            const Ctx ctx = O::ctx(p, flat_group<GM>(p, i));
+            const Ctx ctx = O::ctx(p, flat_group<GM>(p, fx, i));
             o = O::elem4(p, ctx, i, x, x, none);
+        } else if (GM == 6 || GM == 7) {
+            // one division: row of the first element and its offset in that row; the float4 straddles a row end iff off + 3 >= inner
+            int64_t g0, g3;
+            if (GM == 6) {
+                const uint32_t r0 = fd_div(fx.inner, (uint32_t)i), off = (uint32_t)i - r0 * fx.inner.d;
+                const uint32_t a = fd_mod(fx.G, r0), b = a + 1 == fx.G.d ? 0u : a + 1;
+                g0 = a;
+                g3 = off + 3 >= fx.inner.d ? b : a;
+            } else {
+                const int64_t r0 = i / p.inner, off = i - r0 * p.inner;
+                g0 = r0 % p.G;
+                g3 = off + 3 >= p.inner ? (g0 + 1 == p.G ? 0 : g0 + 1) : g0;
+            }
+            const Ctx ctx = O::ctx(p, g0);
+            if (__builtin_expect(g0 == g3, 1)) {
+                o = O::elem4(p, ctx, i, x, x, none);
+            } else {                                   // the float4 straddles a row end (inner >= 4: one row end at most)
+                const Ctx ctx3 = O::ctx(p, g3);
+                const int64_t g1 = flat_group<GM>(p, fx, i + 1), g2 = flat_group<GM>(p, fx, i + 2);
+                o.x = O::elem(p, ctx, i + 0, x.x, 0.f, none);
+                o.y = O::elem(p, g1 == g0 ? ctx : ctx3, i + 1, x.y, 0.f, none);
+                o.z = O::elem(p, g2 == g0 ? ctx : ctx3, i + 2, x.z, 0.f, none);
+                o.w = O::elem(p, ctx3, i + 3, x.w, 0.f, none);
+            }
         } else {
             Ctx ctx[4];
             Acc acc[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                ctx[k] = O::ctx(p, flat_group<GM>(p, i + k));
+                ctx[k] = O::ctx(p, flat_group<GM>(p, fx, i + k));
                 acc[k] = none;
             }
             o = O::elem4c(p, ctx, i, x, x, acc);
@@ -83,7 +115,7 @@ __global__ __launch_bounds__(BS) void k_flat_fwd(Params p, int64_t nv, int rem) 
         Acc none = O::template init<Acc>();
         for (int k = 0; k < rem; ++k) {
             const int64_t i = nv * 4 + k;
-            const Ctx ctx = O::ctx(p, flat_group<(GM | 1)>(p, i));
+            const Ctx ctx = O::ctx(p, (i / p.inner) % p.G);
             const float r = O::elem(p, ctx, i, p.P[i], 0.f, none);
             if (O::kStore) p.out[i] = r;
         }
@@ -94,7 +126,7 @@ __global__ __launch_bounds__(BS) void k_flat_fwd(Params p, int64_t nv, int rem) 
 //  Column tile, software-pipelined.  Block of NW waves owns RB rows x 256 columns; a lane keeps 4 fixed columns; wave w
 //  walks rows w, w + NW, ...; U rows per iteration and stream.  Partial layout as in col_tile_body: (row-block, column).
 // ------------------------------------------------------------------------------------------
-template <int OP, int NT, int U, int NW>
+template <int OP, int NT, int U, int NW, int UA = 0>
 __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64_t RB, int64_t nbx) {
     using O = OpT<OP>;
     __shared__ Acc lds[O::kReduce ? NW * 256 : 1];
@@ -102,8 +134,14 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t b = blockIdx.x;
     const int64_t by = b / nbx, bx = b - by * nbx;
-    const int64_t col0 = (bx * 64 + lane) * 4;
-    const bool active = col0 < C;            // C % 4 == 0: a float4 never straddles a row end
+    const int64_t col0n = (bx * 64 + lane) * 4;
+    const bool active = col0n < C;
+    // UA = 0: C % 4 == 0, a float4 never straddles a row end.  UA = 1 (any C >= 4): rows start on any 4-byte phase
+    // (dword-aligned float4 access), and the lane whose float4 would cross the row end takes the LAST four columns instead:
+    // its first `kdup` elements repeat the previous lane's -- same inputs, same outputs (the stores write identical
+    // values), and their accumulators are simply not emitted.
+    const int64_t col0 = (UA && col0n + 4 > C) ? C - 4 : col0n;
+    const int kdup = (int)(col0n - col0);
     const int64_t r0 = by * RB;
     const int64_t r1 = (r0 + RB < p.outer) ? r0 + RB : p.outer;
     Acc acc[4];
@@ -118,9 +156,9 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
         if (groups > 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                xa[u] = load4<NT>(p.P + i0 + u * step);
+                xa[u] = load4x<NT, UA>(p.P + i0 + u * step);
                 da[u] = xa[u];
-                if (O::kDy) da[u] = load4<NT>(p.dy + i0 + u * step);
+                if (O::kDy) da[u] = load4x<NT, UA>(p.dy + i0 + u * step);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -139,9 +177,9 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
                 const int64_t in0 = i0 + U * step;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    xn[u] = load4<NT>(p.P + in0 + u * step);
+                    xn[u] = load4x<NT, UA>(p.P + in0 + u * step);
                     dn[u] = xn[u];
-                    if (O::kDy) dn[u] = load4<NT>(p.dy + in0 + u * step);
+                    if (O::kDy) dn[u] = load4x<NT, UA>(p.dy + in0 + u * step);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                // the next group's loads stay ahead of this phase's stores
@@ -149,7 +187,7 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
             for (int u = 0; u < U; ++u) {
                 const int64_t i = i0 + u * step;
                 const float4 ov = O::elem4c(p, ctx, i, xc[u], dc[u], acc);
-                if (O::kStore) store4<NT>(p.out + i, ov);
+                if (O::kStore) store4x<NT, UA>(p.out + i, ov);
             }
             ++g;
             i0 += U * step;
@@ -162,11 +200,11 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
             }
         }
         for (int t = groups * U; t < cnt; ++t) {              // at most U - 1 leftover rows
-            const float4 x = load4<NT>(p.P + i0);
+            const float4 x = load4x<NT, UA>(p.P + i0);
             float4 d = x;
-            if (O::kDy) d = load4<NT>(p.dy + i0);
+            if (O::kDy) d = load4x<NT, UA>(p.dy + i0);
             const float4 ov = O::elem4c(p, ctx, i0, x, d, acc);
-            if (O::kStore) store4<NT>(p.out + i0, ov);
+            if (O::kStore) store4x<NT, UA>(p.out + i0, ov);
             i0 += step;
         }
     }
@@ -180,7 +218,7 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
                 Acc r = lds[lane * 4 + k];
 #pragma unroll
                 for (int ww = 1; ww < NW; ++ww) O::merge(r, lds[ww * 256 + lane * 4 + k]);   // fixed wave order
-                write_partial_t<OP>(p, by * C + col0 + k, r);
+                if (!UA || k >= kdup) write_partial_t<OP>(p, by * C + col0 + k, r);
             }
         }
     }
@@ -438,6 +476,181 @@ __global__ __launch_bounds__(kBlock) void k_row_tiny(Params p, int64_t R, int L)
                 const int64_t o = GM == 1 ? (int64_t)((uint32_t)myrow / (uint32_t)p.G) : myrow / p.G;
                 const int64_t g = myrow - o * p.G;
                 idx = g * p.outer + o;                  // group-major partials (see row_small_body); direct emit has outer == 1
+            }
+            write_partial_t<OP>(p, idx, mine);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Rows of 5..1023 elements that do NOT start on 16-byte lines (L % 4 != 0: 7x7 = 49-element activation planes, rows of
+//  1001, ...), scale-gradient ops.  The round-1 row-small kernel walks such rows with 4-byte loads (2.4-4.4 TB/s).  Here a
+//  team of 2^LG lanes owns a row and reads the ALIGNED window of float4s that covers it -- [row*L & ~3, (row*L + L + 3) & ~3) --
+//  V float4 per lane, every load of the wave's U rows issued up front; the (at most two) edge float4s of a row run the same
+//  float4 element path with their outside elements replaced by neutral ones, and store their inside elements one by one, so
+//  neighbouring rows never write the same address.  The window's last float4 may reach past the END OF THE TENSOR when
+//  numel % 4 != 0: that one float4 is loaded element by element.  Reduction and emit as in k_row_tiny.
+// ------------------------------------------------------------------------------------------
+template <int LG>
+__device__ __forceinline__ void team_reduce_std(Acc& acc) {     // every lane of a 2^LG-lane team <- team total (standard merge)
+    if (LG <= 4) {
+        dpp_team_reduce<LG>(acc);
+    } else {
+        dpp_row_reduce(acc);
+#pragma unroll
+        for (int off = 16; off < (1 << LG); off <<= 1) {
+            const uint32_t a = __shfl_xor(acc.a, off, 64), b = __shfl_xor(acc.b, off, 64);
+            const float c = __shfl_xor(acc.c, off, 64);
+            acc.a = a > acc.a ? a : acc.a;
+            acc.b += b;
+            acc.c += c;
+        }
+    }
+}
+
+template <class O>
+__device__ __forceinline__ float4 apply4(const Params& p, const Ctx& ctx, int64_t i, const float4& x, const float4& d, Acc& acc) {
+    float4 r;
+    if constexpr (O::kVec4) {
+        r = O::elem4(p, ctx, i, x, d, acc);
+    } else {
+        r.x = O::elem(p, ctx, i + 0, x.x, O::kDy ? d.x : 0.f, acc);
+        r.y = O::elem(p, ctx, i + 1, x.y, O::kDy ? d.y : 0.f, acc);
+        r.z = O::elem(p, ctx, i + 2, x.z, O::kDy ? d.z : 0.f, acc);
+        r.w = O::elem(p, ctx, i + 3, x.w, O::kDy ? d.w : 0.f, acc);
+    }
+    return r;
+}
+
+// rarely executed paths of k_row_win as rolled loops (the kernel is instantiated for 10 geometries; unrolled they are 40 % of its code)
+__device__ __forceinline__ float4 load_tail4(const float* base, int64_t i0, int64_t n) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < 4; ++k) {
+        const float v = i0 + k < n ? base[i0 + k] : 0.f;
+        t.x = k == 0 ? v : t.x;
+        t.y = k == 1 ? v : t.y;
+        t.z = k == 2 ? v : t.z;
+        t.w = k == 3 ? v : t.w;
+    }
+    return t;
+}
+template <class O>
+__device__ __forceinline__ void edge_scalar4(const Params& p, const Ctx& ctx, int64_t i0, int64_t b, int64_t e, const float4& x,
+                                             const float4& d, Acc& acc) {
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = i0 + k;
+        const float xv = k == 0 ? x.x : (k == 1 ? x.y : (k == 2 ? x.z : x.w));
+        const float dv = k == 0 ? d.x : (k == 1 ? d.y : (k == 2 ? d.z : d.w));
+        if (i >= b && i < e) {
+            const float r = O::elem(p, ctx, i, xv, O::kDy ? dv : 0.f, acc);
+            if (O::kStore) p.out[i] = r;
+        }
+    }
+}
+
+template <int OP, int NT, int LG, int V, int U>
+__global__ __launch_bounds__(kBlock) void k_row_win(Params p, FastDiv fG, int64_t R, int L, int64_t n) {
+    using O = OpT<OP>;
+    static_assert(O::kStdMerge, "DPP / shuffle team reduction of the standard accumulator");
+    constexpr int lpr = 1 << LG, tpw = 64 >> LG;
+    static_assert(U <= lpr, "one finishing lane per (team, pass)");
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int team = lane >> LG, li = lane & (lpr - 1);
+    const int64_t wave_base = ((int64_t)blockIdx.x * kWavesPerBlock + wv) * (tpw * U);
+    if (wave_base >= R) return;                        // wave-uniform
+    float4 x[U][V], d[U][V];
+    int64_t row[U], b[U], w0[U];
+    int nwin[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        row[u] = wave_base + u * tpw + team;
+        const int64_t rr = row[u] < R ? row[u] : R - 1;      // clamp: the loads stay unconditional
+        b[u] = rr * (int64_t)L;
+        w0[u] = b[u] >> 2;
+        nwin[u] = (int)(((b[u] + L + 3) >> 2) - w0[u]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int j = li + v * lpr;
+            const int64_t i0 = (w0[u] + (j < nwin[u] ? j : 0)) * 4;
+            if (__builtin_expect(i0 + 4 <= n, 1)) {
+                x[u][v] = load4<NT>(p.P + i0);
+                d[u][v] = x[u][v];
+                if (O::kDy) d[u][v] = load4<NT>(p.dy + i0);
+            } else {                                          // the one float4 that straddles the end of the tensor
+                x[u][v] = load_tail4(p.P, i0, n);
+                d[u][v] = O::kDy ? load_tail4(p.dy, i0, n) : x[u][v];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Acc acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        acc[u] = O::template init<Acc>();
+        if (row[u] < R) {
+            const int64_t g = p.outer == 1 ? row[u] : (int64_t)fd_mod(fG, (uint32_t)row[u]);
+            const Ctx ctx = O::ctx(p, g);
+            const int64_t e = b[u] + L;
+            const int ph = (int)(b[u] & 3);               // phase of the row start inside its first float4
+            const bool neutral_ok = ctx.fast != 0 && p.lam == p.lam;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int j = li + v * lpr;
+                bool act = j < nwin[u];
+                const int off = j * 4 - ph;                 // offset of this float4's first element from the row start
+                const bool full = off >= 0 && off + 4 <= L;
+                const int64_t i0 = (w0[u] + j) * 4;
+                float4 xx = x[u][v], dd = d[u][v];
+                // An edge float4 runs the SAME float4 path with its outside elements made neutral: x = s/2 gives q = 0,
+                // out = 0 (max|q| unchanged) and dy = +Inf is "ratio >= lambda" for every lambda, so it casts no vote --
+                // valid when s is inside the exact-division window (ctx.fast) and lambda is not NaN; else element by element.
+                // Wave-uniform branch: waves without an edge float4 in this slot (all of them when L % 4 == 0) skip it.
+                if (__builtin_amdgcn_ballot_w64(act && !full) != 0) {
+                    if (act && !full) {
+                        if (__builtin_expect(neutral_ok, 1)) {
+                            const float xn = 0.5f * ctx.s, dn = __builtin_inff();
+                            if (off + 0 < 0 || off + 0 >= L) { xx.x = xn; dd.x = dn; }
+                            if (off + 1 < 0 || off + 1 >= L) { xx.y = xn; dd.y = dn; }
+                            if (off + 2 < 0 || off + 2 >= L) { xx.z = xn; dd.z = dn; }
+                            if (off + 3 < 0 || off + 3 >= L) { xx.w = xn; dd.w = dn; }
+                        } else {
+                            edge_scalar4<O>(p, ctx, i0, b[u], e, xx, dd, acc[u]);
+                            act = false;
+                        }
+                    }
+                }
+                if (act) {
+                    const float4 r = apply4<O>(p, ctx, i0, xx, dd, acc[u]);
+                    if (O::kStore) {
+                        if (__builtin_expect(full, 1)) {
+                            store4<NT>(p.out + i0, r);
+                        } else {                              // neighbouring rows own the other elements of this float4
+                            if (off + 0 >= 0 && off + 0 < L) p.out[i0 + 0] = r.x;
+                            if (off + 1 >= 0 && off + 1 < L) p.out[i0 + 1] = r.y;
+                            if (off + 2 >= 0 && off + 2 < L) p.out[i0 + 2] = r.z;
+                            if (off + 3 >= 0 && off + 3 < L) p.out[i0 + 3] = r.w;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (O::kReduce) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) team_reduce_std<LG>(acc[u]);
+        Acc mine = acc[0];
+#pragma unroll
+        for (int u = 1; u < U; ++u)
+            if (li == u) mine = acc[u];
+        const int64_t myrow = wave_base + li * tpw + team;
+        if (li < U && myrow < R) {
+            int64_t idx = myrow;                        // outer == 1: partial index == row == group
+            if (p.outer != 1) {
+                const uint32_t o = fd_div(fG, (uint32_t)myrow), g = (uint32_t)myrow - o * fG.d;
+                idx = (int64_t)g * p.outer + o;         // group-major partials (see row_small_body)
             }
             write_partial_t<OP>(p, idx, mine);
         }

@@ -35,6 +35,26 @@ __device__ __forceinline__ void store4(float* p, const float4& v) {
     }
 }
 
+// float4 access at an address that is only 4-byte aligned (one global_load_dwordx4 / global_store_dwordx4: global memory
+// needs dword alignment only; a wave's 1 KB access then touches 9 lines instead of 8)
+typedef float v4f_u __attribute__((ext_vector_type(4), aligned(4)));
+template <int NT, int UA>
+__device__ __forceinline__ float4 load4x(const float* p) {
+    if (!UA) return load4<NT>(p);
+    const v4f_u v = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4f_u*>(p)) : *reinterpret_cast<const v4f_u*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <int NT, int UA>
+__device__ __forceinline__ void store4x(float* p, const float4& v) {
+    if (!UA) {
+        store4<NT>(p, v);
+        return;
+    }
+    const v4f_u t = {v.x, v.y, v.z, v.w};
+    if (NT) __builtin_nontemporal_store(t, reinterpret_cast<v4f_u*>(p));
+    else *reinterpret_cast<v4f_u*>(p) = t;
+}
+
 // TAIL = 1: rows whose last chunk carries a folded tail, or whose chunks do not start on a 16-byte line (scalar head / tail
 // elements).  Rows without either (the BENCH shape, rows of 2^k elements, ...) run the TAIL = 0 instantiation, which keeps the
 // registers of the round-1 kernel (the hoisted tail loads cost 7-14 VGPRs).

@@ -32,7 +32,11 @@ import torch.distributed as dist
 
 
 class GradBucket:
-    """Flat fp32 bucket over a fixed parameter list; grads become views into it."""
+    """Flat fp32 bucket over a fixed parameter list; grads become views into it.  Every view starts on a 256-byte
+    boundary (the kernels' float4 paths need 16-byte aligned gradient buffers, lq_hip.h; one-element scales would
+    otherwise shift everything behind them); the padding stays zero and rides through the all-reduce."""
+
+    ALIGN = 64          # floats
 
     def __init__(self, params: Sequence[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -40,14 +44,17 @@ class GradBucket:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
         self.sizes = [p.numel() for p in self.params]
-        self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)
-        self.views = []
+        self.offsets = []
         off = 0
-        for p, n in zip(self.params, self.sizes):
-            v = self.flat[off:off + n].view_as(p)
+        for n in self.sizes:
+            self.offsets.append(off)
+            off += -(-n // self.ALIGN) * self.ALIGN
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.views = []
+        for p, n, o in zip(self.params, self.sizes, self.offsets):
+            v = self.flat[o:o + n].view_as(p)
             self.views.append(v)
             p.grad = v            # autograd accumulates in place into the bucket
-            off += n
 
     def zero_(self):
         self.flat.zero_()
@@ -142,12 +149,8 @@ class DataParallel:
         self._hooks_on = True
         self._synced = False
         limit = max(int(bucket_mb * (1 << 20) / 4), 1)
-        offsets = []
-        off = 0
-        for n in self.bucket.sizes:
-            offsets.append(off)
-            off += n
-        hi = off
+        offsets = self.bucket.offsets
+        hi = self.bucket.flat.numel()
         cur_lo, cur_params = hi, []
         for idx in range(len(self.bucket.params) - 1, -1, -1):
             cur_lo = offsets[idx]

@@ -292,7 +292,7 @@ def main(argv=None):
             "metric": "images/sec end-to-end training step (synthetic data)", "config": args.config, "mode": args.mode,
             "value": world * args.batch * args.steps / dt, "unit": "images/s", "n_gpus": world,
             "ms_per_step": dt / args.steps * 1e3, "per_gpu_batch": args.batch, "orientation": args.orientation,
-            "loss_term": args.loss, "quantized_elements": n_q, "final_loss": float(loss), "ddp_mode": args.ddp_mode,
+            "loss_term": args.loss, "quantized_elements": n_q, "final_loss": float(loss.detach()), "ddp_mode": args.ddp_mode,
             "hipgraph": bool(args.graph), "graph_collectives": bool(args.graph_collectives), "batched": bool(args.batched),
             "backend": (args.backend if use_dist else None),
             "channels_last": bool(args.channels_last)}))

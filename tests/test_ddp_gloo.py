@@ -78,7 +78,7 @@ def _worker(rank, world, port, mode, out_dir):
             model.W.add_(1.0)
     # mode A with tiny sub-buckets: every parameter is its own overlapped all-reduce; mode B: one bucket
     dp = DataParallel(model, mode=mode, scale_grad_fn=_oracle_scale_grad, bucket_mb=(1e-5 if mode == "A" else 25.0))
-    assert len(dp._ranges) == (3 if mode == "A" else 1)
+    assert len(dp._ranges) == (4 if mode == "A" else 1)       # views are padded to 64 floats: W, b and both scales
     g = torch.Generator().manual_seed(123)
     X = torch.randn(8, 12, generator=g)
     Y = torch.randn(8, 5, generator=g)
@@ -188,11 +188,13 @@ def test_grad_bucket_single_process():
     from learned_quantization_amd.ddp import GradBucket
     ps = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))]
     b = GradBucket(ps)
-    assert b.flat.numel() == 17
+    assert b.offsets == [0, 64] and b.flat.numel() == 128                      # every view starts on a 256-byte boundary
+    assert all(v.data_ptr() % 16 == 0 for v in b.views)
     (ps[0].sum() * 2 + ps[1].sum() * 3).backward()
-    assert torch.all(b.flat[:12] == 2) and torch.all(b.flat[12:] == 3)       # autograd accumulated into the bucket
+    assert torch.all(b.flat[:12] == 2) and torch.all(b.flat[64:69] == 3)      # autograd accumulated into the bucket
+    assert torch.count_nonzero(b.flat) == 17                                   # the padding stays zero
     ps[1].grad = torch.full((5,), 7.0)                                         # someone re-allocated a grad
     b.gather_()
-    assert torch.all(b.flat[12:] == 7) and ps[1].grad.data_ptr() == b.views[1].data_ptr()
+    assert torch.all(b.flat[64:69] == 7) and ps[1].grad.data_ptr() == b.views[1].data_ptr()
     b.zero_()
     assert torch.count_nonzero(b.flat) == 0

@@ -140,3 +140,15 @@ def test_bench_force_dist_one_rank_rccl():
     out = _run_script([os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-extras"])
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 1e5 and line["roofline"]["frac"] > 0.5
+
+
+@pytest.mark.parametrize("mode,loss", [("nqcl", "maxbin"), ("cl", "difference")])
+def test_one_rank_rccl_penalty_injection_on_bucket_views(mode, loss):
+    """The batched penalty kernels write straight into the data-parallel bucket's gradient views: every view must satisfy the
+    C ABI's 16-byte alignment (one-element scales sit between the tensors), eager and graphed."""
+    import json
+    for extra in ([], ["--graph"]):
+        out = _run_script(["-m", "learned_quantization_amd.train", "--config", "cifar", "--mode", mode, "--loss", loss, "--value", "1e-11",
+                           "--rate", "1e-7", "--batch", "32", "--steps", "4", "--warmup", "4", "--batched", "--force-dist"] + extra)
+        line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        assert line["backend"] == "nccl" and np.isfinite(line["final_loss"])

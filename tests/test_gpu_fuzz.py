@@ -253,14 +253,21 @@ def test_int32_view_saturates(dev):
 def _rand_streaming_case(rng):
     """Random descriptor of 4.2-6 M elements that lands in one of the streaming-size forms (csrc/lq_stream2.hpp): column tile
     (any C % 4 == 0 > 64, ragged row counts), periodic columns (C <= 64, any C), tiny rows (L in 8..64, L % 4 == 0), rows of
-    68..1020 (flat forward), ragged long rows (TAIL instantiation of the row stream)."""
-    kind = int(rng.integers(0, 5))
+    68..1020 (flat forward), ragged long rows (TAIL instantiation of the row stream), rows of 5..1023 with L % 4 != 0."""
+    kind = int(rng.integers(0, 6))
     n = int(rng.integers(4_200_000, 6_000_000))
+    if kind == 5:                                   # rows of 5..1023 elements off the 16-byte grid: straddling flat forward + row windows
+        L = int(rng.integers(5, 1024))
+        L += 1 if L % 4 == 0 else 0
+        if rng.integers(0, 2) or L < 16:
+            return (n // L, L), "rowwise"
+        outer = int(rng.integers(2, 6))
+        return (outer, n // (L * outer), L), "columnwise"
     if kind == 0:                                   # column tile
         inner = int(rng.choice([1, 1, 2, 4, 6, 8, 12]))
         G = int(rng.integers(17, 700)) * 4 // (4 if inner % 4 == 0 else 1)
         G = max(G, 68 // inner + 1)
-        while (G * inner) % 4 != 0:
+        while (G * inner) % 4 != 0 and rng.integers(0, 2):     # half of the cases keep C % 4 != 0 (dword-aligned float4 tile)
             G += 1
         outer = max(n // (G * inner), 2)
         return (outer, G, inner), "columnwise"

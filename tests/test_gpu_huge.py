@@ -84,3 +84,29 @@ def test_rows_longer_than_2_to_30_with_per_row_scales():
             assert torch.equal(out[r, a:b], torch.floor(P[r, a:b] / s[r]) * s[r])
     _, out_o = O.fq_forward(P[:, L - 3000:].cpu().numpy(), s.cpu().numpy())
     np.testing.assert_array_equal(out[:, L - 3000:].cpu().numpy(), out_o)
+
+
+@pytest.mark.parametrize("L", [1028, 1029])
+def test_flat_forward_beyond_2_to_32_elements(L):
+    """More than 2^32 elements in rows that are not whole 128-byte lines: the line-aligned flat forward with 64-bit group
+    arithmetic (k_flat_fwd group modes 2 and 7 of csrc/lq_stream2.hpp; L = 1029: float4s straddle row ends)."""
+    import learned_quantization_amd as lq
+    dev = torch.device("cuda:0")
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
+        pytest.skip("needs ~40 GB of device memory")
+    R = 4180000
+    assert R * L > 2 ** 32
+    g = torch.Generator(device=dev).manual_seed(3)
+    P = torch.empty(R, L, device=dev)
+    rows = 1 << 18
+    for a in range(0, R, rows):
+        b = min(R, a + rows)
+        P[a:b] = torch.randn(b - a, L, device=dev, generator=g) * 0.05
+    s = (torch.rand(R, 1, device=dev, generator=g) * 9e-3 + 1e-3)
+    out = lq.fq_forward(P, s)
+    for a in range(0, R, rows):
+        b = min(R, a + rows)
+        assert torch.equal(out[a:b], torch.floor(P[a:b] / s[a:b]) * s[a:b]), f"rows {a}..{b}"
+    for a in (0, (2 ** 32) // L - 2, R - 3):                                  # oracle across the 2^32 boundary and at both ends
+        _, out_o = O.fq_forward(P[a:a + 3].cpu().numpy(), s[a:a + 3].cpu().numpy())
+        np.testing.assert_array_equal(out[a:a + 3].cpu().numpy(), out_o)

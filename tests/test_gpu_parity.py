@@ -137,6 +137,26 @@ STREAM2_SHAPES = [
     ((1100, 4100), "rowwise"),         # row stream, 4-element tail folded into the last chunk (loads hoisted: TAIL instantiation)
     ((1100, 4099), "rowwise"),         # row stream, chunks off the 16-byte grid: scalar head / tail elements
     ((3, 1500001), "rowwise"),         # long ragged rows, many chunks
+    ((4200, 1001), "rowwise"),         # row-small rows off the 16-byte grid: flat K1 whose float4s may straddle ONE row end (mode 6)
+    ((3, 1400, 1001), "columnwise"),   # the same with outer > 1: group = (i / inner) % G wraps around
+    ((250001, 17), "rowwise"),         # 17-element rows: every 4th/5th float4 straddles, numel % 4 == 1
+    ((840001, 5), "rowwise"),          # 5-element rows: EVERY float4 straddles a row end
+    ((1030, 4100), "columnwise"),      # inner = 1, G = 4100: scale-float4 forward with the invariant-divisor modulo
+    # rows off the 16-byte grid, scale-gradient ops: aligned float4 windows (k_row_win), team sizes 2..64 lanes, 1..5 float4 per lane
+    ((43, 2048, 49), "columnwise"),    # 7x7 activation planes, outer > 1: 16 lanes per row, group-major partials
+    ((90001, 49), "rowwise"),          # the same rows with outer == 1 (direct emit), numel % 4 == 1: the tensor ends inside a float4
+    ((17000, 253), "rowwise"),         # widest window 64 float4: 64 lanes x 1, two rows per wave
+    ((16500, 257), "rowwise"),         # 65 float4: 64 lanes x 2
+    ((8500, 515), "rowwise"),          # 64 lanes x 3
+    ((6000, 777), "rowwise"),          # 64 lanes x 4
+    ((4300, 1023), "rowwise"),         # 257 float4: 64 lanes x 5
+    ((140001, 30), "rowwise"),         # 8 lanes per row; L % 4 == 2: rows start on two of the four phases only
+    # column tiles whose rows are off the 16-byte grid (C % 4 != 0): dword-aligned float4 access, the last lane re-reads columns
+    ((70000, 67), "columnwise"),       # C = 67: one column block, the last lane repeats one column
+    ((33000, 130), "columnwise"),      # C % 4 == 2
+    ((4200, 1001), "columnwise"),      # 4 column blocks, the last one 233 wide
+    ((1100, 4099), "columnwise"),      # 17 column blocks, the last one 3 columns wide (its only lane repeats one column)
+    ((2100, 682, 3), "columnwise"),    # inner = 3: C = 2046
 ]
 
 
@@ -391,3 +411,48 @@ def test_mnist_real_weights_backward(mnist_weights, dev, orient):
         dy = (rng.normal(0, 1, size=P.shape) * 10.0 ** rng.uniform(-6, -2, size=P.shape)).astype(np.float32)
         for lam in (1e-11, 1e-10, 1e-6, 1e-3):
             _check_case(P, s, dy, lam, dev, f"{name} {orient} lam={lam}")
+
+
+def test_profile_events_stamp_the_kernel_itself(dev):
+    """lq_profile_events(start, stop): the row-stream traversal is launched through hipExtLaunchKernelGGL and the two events
+    carry the kernel's own begin / end -- what bench.py's roofline leg relies on.  The interval must be the kernel (tens of
+    microseconds on the 154 MB tensor), not the call (which also holds the finalize launch) and not zero; switching the hook
+    off again must leave later launches unstamped."""
+    from learned_quantization_amd import _hip
+    lib = _hip.load()
+    x = torch.rand(256, 3, 224, 224, device=dev) * 255.0
+    dy = torch.randn(256, 3, 224, 224, device=dev) * 1e-3
+    out = torch.empty_like(x)
+    s = torch.tensor([0.5, 1.0, 2.0], device=dev)
+    ds = torch.empty(3, device=dev)
+    ws = torch.empty(lib.lq_workspace_bytes(256, 3, 50176), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def live():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        return e
+    times = {}
+    for name in ("fwd", "bwd"):
+        vals = []
+        for _ in range(6):
+            a, b = live(), live()
+            torch.cuda.synchronize()
+            lib.lq_profile_events(a.cuda_event, b.cuda_event)
+            if name == "fwd":
+                rc = lib.lq_fq_forward(x.data_ptr(), s.data_ptr(), out.data_ptr(), None, 0, 256, 3, 50176, None)
+            else:
+                rc = lib.lq_fq_scale_grad(x.data_ptr(), s.data_ptr(), dy.data_ptr(), 1e-11, ds.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                          256, 3, 50176, None)
+            lib.lq_profile_events(None, None)
+            assert rc == 0
+            torch.cuda.synchronize()
+            vals.append(a.elapsed_time(b) * 1e3)
+        times[name] = sorted(vals)[len(vals) // 2]
+    # 308 MB at 4-7 TB/s
+    assert 40.0 < times["fwd"] < 80.0 and 40.0 < times["bwd"] < 80.0, times
+    a, b = live(), live()
+    torch.cuda.synchronize()
+    assert lib.lq_fq_forward(x.data_ptr(), s.data_ptr(), out.data_ptr(), None, 0, 256, 3, 50176, None) == 0     # hook off
+    torch.cuda.synchronize()
+    assert abs(a.elapsed_time(b)) < 0.03          # the two records were back to back: nothing stamped them again

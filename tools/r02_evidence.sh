@@ -29,6 +29,11 @@ if [ $part = all ] || [ $part = e2e ]; then
   timeout -k 10 200 python3 -m learned_quantization_amd.train --config cifar --mode nqcl --loss maxbin --value 1e-11 --rate 1e-7 --batch 256 --steps 60 --warmup 15 --batched --graph 2>> $out/e2e.err | grep '^{' >> $out/e2e_cifar.jsonl
   timeout -k 10 300 python3 -m learned_quantization_amd.train --config resnet50 --value 1e-11 --value-coarse 1e-10 --batch 32 --steps 12 --warmup 4 --batched --graph 2>> $out/e2e.err | grep '^{' >> $out/e2e_cifar.jsonl
   timeout -k 10 300 python3 -m learned_quantization_amd.train --config imagenette --batch 64 --steps 12 --warmup 4 --batched --graph 2>> $out/e2e.err | grep '^{' >> $out/e2e_cifar.jsonl
+  # the per-GPU batch sizes BASELINE.json's configs name: ResNet-18-like bs 256, CIFAR nested quantization + loss term 1024 / 8 = 128,
+  # ResNet-50-like 2048 / 8 = 256 (both data-parallel configs also on the one-rank RCCL group)
+  timeout -k 10 400 python3 -m learned_quantization_amd.train --config imagenette --batch 256 --steps 8 --warmup 3 --batched --graph 2>> $out/e2e.err | grep '^{' >> $out/e2e_cifar.jsonl
+  timeout -k 10 200 python3 -m learned_quantization_amd.train --config cifar --mode nqcl --loss maxbin --value 1e-11 --rate 1e-7 --batch 128 --steps 60 --warmup 15 --batched --graph --force-dist 2>> $out/e2e.err | grep '^{' >> $out/e2e_cifar.jsonl
+  timeout -k 10 600 python3 -m learned_quantization_amd.train --config resnet50 --value 1e-11 --value-coarse 1e-10 --batch 256 --steps 6 --warmup 3 --batched --graph --force-dist 2>> $out/e2e.err | grep '^{' >> $out/e2e_cifar.jsonl
   mkdir -p $out/prof_e2e_cifar
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_e2e_cifar -- python3 tools/e2e_knobs.py cifar 256 0 1 > $out/prof_e2e_cifar/run.log 2> $out/prof_e2e_cifar/err.log || exit 1
   echo "e2e part done"
