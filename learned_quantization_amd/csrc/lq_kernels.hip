@@ -70,6 +70,7 @@ struct Plan {
     int64_t C, rps, ysplit;   // column mode
     int per4;           // column mode, C <= 64: geometry admits the float4 grid-stride variant (ysplit % C == 0)
     int64_t np;         // number of partial triples
+    int64_t np_ws;      // row-big at streaming size: partial count of the smallest chunk the launch may choose (workspace bound)
     // finalize geometry (per group)
     int64_t gstride, n1, stride1, n2;
 };
@@ -77,6 +78,7 @@ struct Plan {
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 static bool flat_cols_ok(int64_t C) { return C == 8 || C == 16 || C == 32 || C == 64; }
+static int64_t periodic_blocks(int64_t C) { return C * ((2048 + C / 2) / C); }      // ~2048 blocks, a multiple of C
 
 // Chunks of CH elements per row of length L.  A tail of at most CH/8 elements is folded into the previous chunk (the
 // traversal's last chunk takes whatever remains) instead of getting a block of its own.
@@ -151,6 +153,10 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
                     const int64_t fb = ceil_div(ceil_div(outer * C, 4) + 1, (int64_t)kFlatColsBlock * 2);
                     if (fb * C > pl.np) pl.np = fb * C;
                 }
+                // 64 < C <= 256 at streaming size may run the periodic form (a column tile narrower than 256 columns leaves
+                // lanes idle): one partial per (block, column) for periodic_blocks(C) blocks
+                if (C > 64 && C <= 256 && (double)outer * (double)C >= (double)kPeriodic4Min && periodic_blocks(C) * C > pl.np)
+                    pl.np = periodic_blocks(C) * C;
                 pl.gstride = inner;
                 pl.n1 = nby;
                 pl.stride1 = C;
@@ -175,6 +181,7 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
             }
             pl.CH = pl.bs * 4;
             pl.nc = row_chunks(L, pl.CH);
+            if (pl.bs == 512) pl.np_ws = R * row_chunks(L, 1024);      // launch_traverse may cut such rows into 1024-element chunks
         } else {
             pl.mode = MODE_ROW_SMALL;
             pl.CH = (int)L;
@@ -230,7 +237,7 @@ static int check_desc(int64_t outer, int64_t G, int64_t inner) {
 }
 
 static size_t ws_bytes_for(const Plan& pl) {
-    size_t np = (size_t)pl.np;
+    size_t np = (size_t)(pl.np_ws > pl.np ? pl.np_ws : pl.np);
     np = (np + 63) / 64 * 64;
     return np * 12 + 256;
 }
@@ -239,7 +246,7 @@ static int bind_ws(Params& p, const Plan& pl, void* ws, size_t ws_bytes) {
     if (!ws) return fail(LQ_EWORKSPACE, "workspace is NULL (need %zu bytes)", ws_bytes_for(pl));
     if (!aligned(ws, 16)) return fail(LQ_EALIGN, "workspace must be 16-byte aligned");
     if (ws_bytes < ws_bytes_for(pl)) return fail(LQ_EWORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, ws_bytes_for(pl));
-    size_t np = ((size_t)pl.np + 63) / 64 * 64;
+    size_t np = ((size_t)(pl.np_ws > pl.np ? pl.np_ws : pl.np) + 63) / 64 * 64;
     p.pa = reinterpret_cast<uint32_t*>(ws);
     p.pb = p.pa + np;
     p.pc = reinterpret_cast<float*>(p.pb + np);
@@ -307,7 +314,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         if constexpr (OP == OP_FWD) {
             static const int off_rb = tune_int("LQ_TUNE_S2", 0);
             const int64_t nn = p.outer * p.G * p.inner;
-            if (!(off_rb & 256) && p.G > 1 && pl.L % 32 != 0 && aligned(p.P, 16) && aligned(p.out, 16)) {
+            if (!(off_rb & 256) && p.G > 1 && (pl.L % 32 != 0 || (off_rb & 4096)) && aligned(p.P, 16) && aligned(p.out, 16)) {
                 // rows that are not a whole number of 128-byte lines: one group per float4 when L % 4 == 0 (group mode 0 / 2),
                 // else a float4 may straddle a row end (6 / 7)
                 const int64_t nv = nn >> 2;
@@ -320,7 +327,9 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                     if (pl.L % 4 == 0) {
                         if (ntb) { if (wide) LQ_FLATR(1, 2); else LQ_FLATR(1, 0); }
                         else { if (wide) LQ_FLATR(0, 2); else LQ_FLATR(0, 0); }
-                    } else if (off_rb & 512) {
+                    } else if (!(off_rb & 512)) {
+                        // long rows with L % 4 != 0 keep the row stream (TAIL instantiation): K1 5.8-6.0 TB/s on rows of 1025,
+                        // 2047, 4099, 50177 against 5.4-5.9 for the straddling flat form (development knob 512 selects the latter)
                         return 0;
                     } else {
                         if (ntb) { if (wide) LQ_FLATR(1, 7); else LQ_FLATR(1, 6); }
@@ -424,6 +433,21 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
             else if (nt && OP == OP_FUSED && pl.C >= 16) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             else if (nt) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
+            return check_hip("periodic column launch") ? -1 : 1;
+        }
+        static const int per_cmax = tune_int("LQ_TUNE_PER_CMAX", 256);      // development knob: 0 = always the tile
+        if (pl.C <= per_cmax && pl.C <= 256 && (pl.C < 192 || pl.C % 32 != 0) && periodic_blocks(pl.C) * pl.C <= pl.np) {
+            // 64 < C <= 256: a tile narrower than 256 columns leaves lanes idle and, when C % 32 != 0, starts every row in the
+            // middle of a 128-byte line; the periodic form is a flat line-aligned stream for any C.  Measured (K2 / K4 TB/s,
+            // tile -> periodic): C = 68: 3.2 / 2.9 -> 5.6 / 5.7; 100: 4.3 / 4.0 -> 5.7 / 5.6; 130: 5.0 / 4.3 -> 5.4 / 5.1;
+            // 99 (inner 3): 3.9 / 3.6 -> 5.5 / 5.0; 200, 250: +-3 %; 192 (3 full lines per row): 5.5 / 5.6 -> 5.1 / 5.1, keeps the tile
+            const int64_t nb = periodic_blocks(pl.C);
+            pl.ysplit = nb;               // the finalize that follows must walk the partial layout this launch produces
+            pl.np = nb * pl.C;
+            pl.n1 = nb;
+            if (nt && OP == OP_FUSED) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
+            else if (nt) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, kUp>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
+            else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
             return check_hip("periodic column launch") ? -1 : 1;
         }
         const bool ua = pl.C % 4 != 0;
@@ -530,10 +554,30 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         if (r2 > 0) return LQ_OK;
     }
     if (pl.mode == MODE_ROW_BIG) {
-        const int64_t units = pl.R * pl.nc;
-        if (units > 2147483647ll) return fail(LQ_EINVAL, "too many work units (%lld)", (long long)units);
         // float4 path: 16-byte aligned bases; rows of any length (a scalar head/tail of <= 3 elements re-aligns each chunk)
         const bool vec = aligned(p.P, 16) && (!O::kDy || aligned(p.dy, 16)) && (!O::kStore || aligned(p.out, 16));
+        // Chunk size by row length (streaming sizes, where the plan says 512 threads).  A row is cut into chunks of CH
+        // elements and its last chunk is whatever remains: rows of 2500 elements fill 61 % of two 2048-chunks but 81 % of
+        // three 1024-chunks.  Measured, K4 at 512 -> 256 threads: rows of 2500: 4.4 -> 6.0 TB/s, 3000: 5.1 -> 6.1, 5000: 5.8 ->
+        // 6.3, 6000 (same fill): 6.2 = 6.2; K2 (two float4 per thread, CH = 4096): 5000: 5.7 -> 6.5, 6000: 5.9 -> 6.6, but a
+        // row that is ONE chunk keeps it (2500: 6.8 against 6.3).  The BENCH rows (50176 = 24.5 x 2048) keep 512 threads.
+        static const int tune_chunk = tune_int("LQ_TUNE_CHUNK", 1);     // development knob: 0 = always the plan's block size
+        if (pl.bs == 512 && vec && tune_chunk && !p.direct && !getenv("LQ_TUNE_BS") && pl.np_ws >= pl.R * row_chunks(pl.L, 1024)) {
+            auto fill = [&](int64_t CH) { return (double)pl.L / (double)(row_chunks(pl.L, CH) * CH); };
+            const bool k2_form = (OP == OP_BWD || (OP == OP_FUSED && p.tmode >= 1)) && (double)pl.R * (double)pl.L * 4.0 >= (double)kNtBytes;
+            const bool small = k2_form ? (row_chunks(pl.L, 4096) > 1 && fill(1024) > fill(4096) + 0.1) : (fill(1024) > fill(2048) + 0.05);
+            if (small) {
+                pl.bs = 256;
+                pl.CH = 1024;
+                pl.nc = row_chunks(pl.L, 1024);
+                pl.np = pl.R * pl.nc;              // the finalize that follows must walk the partial layout this launch produces
+                pl.gstride = pl.nc;
+                pl.stride1 = p.G * pl.nc;
+                pl.n2 = pl.nc;
+            }
+        }
+        const int64_t units = pl.R * pl.nc;
+        if (units > 2147483647ll) return fail(LQ_EINVAL, "too many work units (%lld)", (long long)units);
         const int64_t outer_f = pl.R / p.G;
         const int grid3d = (p.G <= 65535 && outer_f <= 65535 && pl.R == outer_f * p.G) ? 1 : 0;
         const dim3 grid = grid3d ? dim3((unsigned)pl.nc, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)units);

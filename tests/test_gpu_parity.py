@@ -157,6 +157,12 @@ STREAM2_SHAPES = [
     ((4200, 1001), "columnwise"),      # 4 column blocks, the last one 233 wide
     ((1100, 4099), "columnwise"),      # 17 column blocks, the last one 3 columns wide (its only lane repeats one column)
     ((2100, 682, 3), "columnwise"),    # inner = 3: C = 2046
+    # 64 < C <= 256: the periodic form (flat stream, LDS combine with H = 256 / C helpers per column)
+    ((42000, 100), "columnwise"),      # C = 100: 2 helpers per column
+    ((17000, 250), "columnwise"),      # C = 250: one helper per column, numel % 4 == 0
+    ((42001, 33, 3), "columnwise"),    # C = 99 with inner = 3, numel % 4 == 3
+    ((21000, 200), "columnwise"),      # C = 200 (C % 32 != 0)
+    ((21900, 192), "columnwise"),      # C = 192 keeps the column tile (3 full lines per row)
 ]
 
 

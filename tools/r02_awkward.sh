@@ -28,7 +28,9 @@ for r in csv.DictReader(open(f)):
 print(f"{tag:18s} ({o},{g},{i})".ljust(44) + " | ".join(f"{row[op][0]:38s} {row[op][1]:7.1f}us {row[op][2]:5.0f}" if op in row else "-" for op in ("0", "1", "2")))
 PY
 }
-if [ "$MIDROWS" = "1" ]; then      # rows of 68..1020 elements with L % 4 == 0 only (A/B of LQ_TUNE_WIN)
+if [ -n "$CASES" ]; then           # CASES="tag:outer,G,inner ..." overrides the lists below
+for c in $CASES; do tag=${c%%:*}; d=${c##*:}; IFS=, read o g i <<< "$d"; run $tag $o $g $i || exit 1; done
+elif [ "$MIDROWS" = "1" ]; then      # rows of 68..1020 elements with L % 4 == 0 only (A/B of LQ_TUNE_WIN)
 run r100     1 327680 100  && run r300   1 114688 300  && run r512    1 65536 512  && run r1000  1 32768 1000 && run o4r196 64 2048 196 || exit 1
 else
 run a49      256 2048 49   && run r17    1 2097152 17  && run r100    1 327680 100 && run r300   1 114688 300 && run r1000  1 32768 1000 && \
