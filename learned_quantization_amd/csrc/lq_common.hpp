@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "lq_hip.h"
+#include "lq_fastdiv.hpp"
 
 namespace lq {
 
@@ -59,27 +60,6 @@ __device__ __forceinline__ uint32_t perm_index(const Params& p, int64_t i) {    
     return (o * p.perm_ci + c) * p.perm_hw + h;
 }
 
-// Division by a launch-invariant 32-bit divisor (Granlund & Montgomery, "Division by invariant integers using
-// multiplication", fig. 4.1): exact for every 32-bit dividend, 5 VALU instead of the ~25 of a 32-bit udiv.  The flat
-// streaming kernels find the group of an element from its flat index with it.
-struct FastDiv {
-    uint32_t d, m, sh1, sh2;
-};
-static inline FastDiv make_fastdiv(uint32_t d) {      // d >= 1
-    FastDiv f;
-    uint32_t l = 0;
-    while (l < 32 && ((uint64_t)1 << l) < d) ++l;
-    f.d = d;
-    f.m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
-    f.sh1 = l < 1 ? l : 1;
-    f.sh2 = l > 1 ? l - 1 : 0;
-    return f;
-}
-__device__ __forceinline__ uint32_t fd_div(const FastDiv& f, uint32_t n) {
-    const uint32_t t = __umulhi(f.m, n);
-    return (t + ((n - t) >> f.sh1)) >> f.sh2;
-}
-__device__ __forceinline__ uint32_t fd_mod(const FastDiv& f, uint32_t n) { return n - fd_div(f, n) * f.d; }
 struct FlatIdx {          // group of flat element i: (i / inner) % G
     FastDiv inner, G;
 };

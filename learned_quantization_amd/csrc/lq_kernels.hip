@@ -352,6 +352,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     if constexpr (OP == OP_FWD) {
         const bool one_group = p.inner % 4 == 0;                                             // a float4 never straddles groups
         const bool scale4 = p.inner == 1 && p.G % 4 == 0 && aligned(p.s, 16) && !(off & 32);   // its 4 scales are one float4
+        const bool scale4u = p.inner == 1 && p.G % 4 != 0 && p.G > 64 && !(off & 8192);       // the same, dword-aligned, may wrap
         const bool cols_pow2 = pl.mode == MODE_COL && pl.per4 && flat_cols_ok(pl.C) && !(off & 64);   // k_flat_cols below: 1-2 % faster
         // rows of 4..1023 elements off the 16-byte grid (row-small mode, L % 4 != 0): a float4 straddles at most one row end
         const bool straddle = pl.mode == MODE_ROW_SMALL && pl.L >= 4 && pl.L % 4 != 0 && !(off & 256);
@@ -365,6 +366,19 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                 if (nt) { if (wide) LQ_FLATS(1, 7); else LQ_FLATS(1, 6); }
                 else { if (wide) LQ_FLATS(0, 7); else LQ_FLATS(0, 6); }
 #undef LQ_FLATS
+                return check_hip("flat forward launch") ? -1 : 1;
+            }
+        }
+        if (scale4u && !(off & 1)) {
+            const int64_t nv = n >> 2;
+            const int rem = (int)(n & 3);
+            const int64_t blocks = ceil_div(nv + (rem ? 1 : 0), 512);
+            if (blocks <= 2147483647ll) {
+                const bool wide = n >= 4294967296ll;
+#define LQ_FLATU(NT_, GM_) hipLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, p, fx, nv, rem)
+                if (nt) { if (wide) LQ_FLATU(1, 9); else LQ_FLATU(1, 8); }
+                else { if (wide) LQ_FLATU(0, 9); else LQ_FLATU(0, 8); }
+#undef LQ_FLATU
                 return check_hip("flat forward launch") ? -1 : 1;
             }
         }
@@ -489,6 +503,29 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     } else {
         // MODE_ROW_SMALL, scale-gradient ops.  Rows off the 16-byte grid (or, development knob 1024, any row of 68..1020
         // elements): aligned float4 windows (lq_stream2.hpp k_row_win)
+        // short rows off the 16-byte grid: one flat window per block (lq_stream2.hpp k_row_seg)
+        // -- when the team-per-row form below would leave too many lanes idle (widest window of a row / team size): measured
+        // K2 / K4 TB/s, team -> block: L = 63 (17 of 32 lanes): 3.6 / 3.8 -> 4.2 / 4.9; 30: 3.5 / 3.9 -> 4.2 / 4.8; 17: 3.9 / 3.9 ->
+        // 4.1 / 4.7; 49 (13 of 16): 4.8 / 4.6 -> 3.5 / 4.3 (keeps the team); 9 with outer = 4: 3.0 / 3.2 -> 2.8 / 3.5
+        bool seg = false;
+        if (pl.L >= 5 && pl.L <= 64 && pl.L % 4 != 0) {
+            const int nw = (int)(pl.L + 6) / 4;
+            int tl = 1;
+            while ((1 << tl) < nw) ++tl;
+            const double eff = (double)nw / (double)(1 << tl);
+            seg = eff < (OP == OP_FUSED ? 0.8 : 0.7);
+        }
+        if (!(off & 16384) && seg && pl.R < 4294967296ll) {
+            constexpr int kSegU = 2;
+            const int rpb = (kBlock * kSegU * 4 - 3) / (int)pl.L;
+            const int64_t blocks = ceil_div(pl.R, (int64_t)rpb);
+            if (blocks <= 2147483647ll) {
+                const FastDiv fL = make_fastdiv((uint32_t)pl.L), fG = make_fastdiv((uint32_t)p.G);
+                if (nt) hipLaunchKernelGGL((k_row_seg<OP, 1, kSegU>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, fL, fG, pl.R, (int)pl.L, rpb, n);
+                else hipLaunchKernelGGL((k_row_seg<OP, 0, kSegU>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, fL, fG, pl.R, (int)pl.L, rpb, n);
+                return check_hip("row-segment launch") ? -1 : 1;
+            }
+        }
         static const int win_all = tune_int("LQ_TUNE_WIN", 1);      // 0: rows with L % 4 == 0 and L > 64 keep the round-1 row-small kernel
         if (!(off & 128) && pl.L >= 5 && pl.R < 4294967296ll && (pl.L % 4 != 0 || (win_all && pl.L > 64))) {
             const int nwin = (int)(pl.L % 4 ? (pl.L + 3 + 3) / 4 : pl.L / 4);     // float4s of the widest window of a row

@@ -16,7 +16,8 @@
 //   k_col_periodic_pipe   the same pipeline for the periodic float4 form (C <= 64).
 //   k_flat_cols       C = 8, 16, 32, 64 as a flat one-shot stream with an xor-shuffle tree over the lanes that share columns
 //                     (K1 and K4; the read-only K2 is faster in the periodic form).
-//   k_row_win         rows of 5..1023 elements off the 16-byte grid (scale-gradient ops): aligned float4 windows per row.
+//   k_row_win         rows of 65..1023 elements of any alignment (scale-gradient ops): aligned float4 windows per row.
+//   k_row_seg         rows of 5..64 elements off the 16-byte grid: one flat window per block, segmented reduction through LDS.
 //   k_row_tiny        rows of <= 64 elements: U passes of rows per wave with all loads up front, DPP team reductions
 //                     (VALU only), ONE emit per wave in which lane (team, u) finishes row (u, team).
 // All of them are used for tensors of >= 4 M elements only (kPeriodic4Min): below that the round-1 bodies run, the same
@@ -37,6 +38,7 @@ namespace lq {
 //            the quotient is the IEEE `/` itself (correctly rounded, ~11 VALU each): building four reciprocal contexts
 //            per thread costs more than it saves when each is used for a single element
 // ------------------------------------------------------------------------------------------
+//     8 / 9: inner == 1 and G % 4 != 0 (G >= 4): as 4 / 5 with a dword-aligned scale float4, element by element where it wraps
 //     6 / 7: long rows that do not start on 16-byte lines (row mode with inner % 4 != 0, e.g. rows of 4100 or 4099 elements):
 //            the row-stream kernel would start every block in the middle of a 128-byte line (each 1 KB wave access then touches
 //            9 lines instead of 8: K1 5.4-5.9 TB/s); as a flat stream every access is line-aligned, a float4 has one group
@@ -73,32 +75,67 @@ __global__ __launch_bounds__(BS) void k_flat_fwd(Params p, FlatIdx fx, int64_t n
                 store_q(p.q, p.q_dtype, i + 2, q.z);
                 store_q(p.q, p.q_dtype, i + 3, q.w);
             }
+        } else if (GM == 8 || GM == 9) {
+            // inner == 1, any G >= 4 (column matrices whose rows are off the 16-byte grid): the scales of a float4 are the four
+            // consecutive entries at column i % G -- one dword-aligned float4 load -- unless the float4 wraps around a row end
+            const int64_t c = GM == 8 ? (int64_t)fd_mod(fx.G, (uint32_t)i) : i % p.G;
+            float4 sv;
+            if (__builtin_expect(c + 4 <= p.G, 1)) {
+                sv = load4x<0, 1>(p.s + c);
+            } else {
+                sv.x = p.s[c];
+                sv.y = p.s[c + 1 < p.G ? c + 1 : c + 1 - p.G];
+                sv.z = p.s[c + 2 < p.G ? c + 2 : c + 2 - p.G];
+                sv.w = p.s[c + 3 < p.G ? c + 3 : c + 3 - p.G];
+            }
+            float4 q;
+            q.x = floorf(x.x / sv.x); q.y = floorf(x.y / sv.y); q.z = floorf(x.z / sv.z); q.w = floorf(x.w / sv.w);   // custom_layers.py:56-59
+            o.x = q.x * sv.x; o.y = q.y * sv.y; o.z = q.z * sv.z; o.w = q.w * sv.w;                                   // :60
+            if (p.q) {
+                store_q(p.q, p.q_dtype, i + 0, q.x);
+                store_q(p.q, p.q_dtype, i + 1, q.y);
+                store_q(p.q, p.q_dtype, i + 2, q.z);
+                store_q(p.q, p.q_dtype, i + 3, q.w);
+            }
         } else if (GM == 0 || GM == 2) {
             const Ctx ctx = O::ctx(p, flat_group<GM>(p, fx, i));
             o = O::elem4(p, ctx, i, x, x, none);
         } else if (GM == 6 || GM == 7) {
             // one division: row of the first element and its offset in that row; the float4 straddles a row end iff off + 3 >= inner
             int64_t g0, g3;
+            uint32_t off6 = 0;
+            int64_t off7 = 0;
             if (GM == 6) {
-                const uint32_t r0 = fd_div(fx.inner, (uint32_t)i), off = (uint32_t)i - r0 * fx.inner.d;
+                const uint32_t r0 = fd_div(fx.inner, (uint32_t)i);
+                off6 = (uint32_t)i - r0 * fx.inner.d;
                 const uint32_t a = fd_mod(fx.G, r0), b = a + 1 == fx.G.d ? 0u : a + 1;
                 g0 = a;
-                g3 = off + 3 >= fx.inner.d ? b : a;
+                g3 = off6 + 3 >= fx.inner.d ? b : a;
             } else {
-                const int64_t r0 = i / p.inner, off = i - r0 * p.inner;
+                const int64_t r0 = i / p.inner;
+                off7 = i - r0 * p.inner;
                 g0 = r0 % p.G;
-                g3 = off + 3 >= p.inner ? (g0 + 1 == p.G ? 0 : g0 + 1) : g0;
+                g3 = off7 + 3 >= p.inner ? (g0 + 1 == p.G ? 0 : g0 + 1) : g0;
             }
-            const Ctx ctx = O::ctx(p, g0);
-            if (__builtin_expect(g0 == g3, 1)) {
-                o = O::elem4(p, ctx, i, x, x, none);
-            } else {                                   // the float4 straddles a row end (inner >= 4: one row end at most)
-                const Ctx ctx3 = O::ctx(p, g3);
-                const int64_t g1 = flat_group<GM>(p, fx, i + 1), g2 = flat_group<GM>(p, fx, i + 2);
-                o.x = O::elem(p, ctx, i + 0, x.x, 0.f, none);
-                o.y = O::elem(p, g1 == g0 ? ctx : ctx3, i + 1, x.y, 0.f, none);
-                o.z = O::elem(p, g2 == g0 ? ctx : ctx3, i + 2, x.z, 0.f, none);
-                o.w = O::elem(p, ctx3, i + 3, x.w, 0.f, none);
+            // ONE straight-line pass with a scale per element and the IEEE `/` (as group modes 4 / 8): a float4 that straddles
+            // a row end takes the same instructions as the others.  (With rows of 49 elements every 12th float4 straddles;
+            // as a divergent branch the per-element path ran in nearly every wave: 4.8 TB/s.)
+            const float s0 = p.s[g0];
+            float s3 = s0;
+            if (g3 != g0) s3 = p.s[g3];
+            float4 sv;
+            sv.x = s0;
+            sv.y = (GM == 6 ? off6 + 1 >= fx.inner.d : off7 + 1 >= p.inner) ? s3 : s0;
+            sv.z = (GM == 6 ? off6 + 2 >= fx.inner.d : off7 + 2 >= p.inner) ? s3 : s0;
+            sv.w = s3;
+            float4 q;
+            q.x = floorf(x.x / sv.x); q.y = floorf(x.y / sv.y); q.z = floorf(x.z / sv.z); q.w = floorf(x.w / sv.w);   // custom_layers.py:56-59
+            o.x = q.x * sv.x; o.y = q.y * sv.y; o.z = q.z * sv.z; o.w = q.w * sv.w;                                   // :60
+            if (p.q) {
+                store_q(p.q, p.q_dtype, i + 0, q.x);
+                store_q(p.q, p.q_dtype, i + 1, q.y);
+                store_q(p.q, p.q_dtype, i + 2, q.z);
+                store_q(p.q, p.q_dtype, i + 3, q.w);
             }
         } else {
             Ctx ctx[4];
@@ -653,6 +690,161 @@ __global__ __launch_bounds__(kBlock) void k_row_win(Params p, FastDiv fG, int64_
                 idx = (int64_t)g * p.outer + o;         // group-major partials (see row_small_body)
             }
             write_partial_t<OP>(p, idx, mine);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+//  Short rows off the 16-byte grid (5 <= L <= 64, L % 4 != 0: 7x7 activation planes, ...), scale-gradient ops.  A team per
+//  row (k_row_win) leaves lanes idle (13 of 16 for L = 49, 5 of 8 for L = 17) and reads the float4 shared by two rows twice.
+//  Here a BLOCK owns `rpb` whole consecutive rows -- one contiguous span -- and reads the aligned window that covers it as a
+//  flat stream, U float4 per thread, all loads up front.  A float4 lies in at most two rows (L >= 4): each element gets the
+//  context of its row (field-wise selects, no arrays of structs), elements outside the span become neutral (see k_row_win),
+//  and the thread ends with one accumulator for "its first row" (A) and one for the next (B).  Both go to LDS; thread r then
+//  walks the entries of local row r in ascending order -- a fixed order, so the result is run-to-run bit-stable -- and
+//  writes ONE partial (or the finished outputs) for the row.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ Ctx ctx_select(bool b, const Ctx& x, const Ctx& y) {      // b ? x : y, field by field
+    Ctx c;
+    c.s = b ? x.s : y.s;
+    c.r = b ? x.r : y.r;
+    c.fast = b ? x.fast : y.fast;
+    c.k0 = b ? x.k0 : y.k0;
+    c.k1 = b ? x.k1 : y.k1;
+    c.lam_hi = b ? x.lam_hi : y.lam_hi;
+    c.sure_ok = b ? x.sure_ok : y.sure_ok;
+    return c;
+}
+__device__ __forceinline__ void acc_merge_std(Acc& r, const Acc& o) {
+    r.a = o.a > r.a ? o.a : r.a;
+    r.b += o.b;
+    r.c += o.c;
+}
+
+template <int OP, int NT, int U>
+__global__ __launch_bounds__(kBlock) void k_row_seg(Params p, FastDiv fL, FastDiv fG, int64_t R, int L, int rpb, int64_t n) {
+    using O = OpT<OP>;
+    static_assert(O::kStdMerge && O::kVec4c, "standard accumulator, per-element contexts");
+    __shared__ Acc lds[O::kReduce ? kBlock * U * 2 : 1];
+    const int t = (int)threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * rpb;                      // < R by the grid size
+    const int rows = (int)(R - row0 < (int64_t)rpb ? R - row0 : (int64_t)rpb);
+    const int64_t b0 = row0 * (int64_t)L;
+    const int ph = (int)(b0 & 3);
+    const int64_t w0 = b0 >> 2;
+    const int span = rows * L;                                           // elements of this block: (ph + span + 3) / 4 <= kBlock * U float4
+    const int nwin = (ph + span + 3) >> 2;
+    float4 x[U], d[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = t + u * kBlock;
+        const int64_t i0 = (w0 + (j < nwin ? j : 0)) * 4;
+        if (__builtin_expect(i0 + 4 <= n, 1)) {
+            x[u] = load4<NT>(p.P + i0);
+            d[u] = x[u];
+            if (O::kDy) d[u] = load4<NT>(p.dy + i0);
+        } else {                                                         // the one float4 that straddles the end of the tensor
+            x[u] = load_tail4(p.P, i0, n);
+            d[u] = O::kDy ? load_tail4(p.dy, i0, n) : x[u];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool lam_ok = p.lam == p.lam;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = t + u * kBlock;
+        Acc aA = O::template init<Acc>(), aB = aA;
+        if (j < nwin) {
+            const int off = j * 4 - ph;                                  // local index of this float4's first element (>= -3)
+            const int e0 = off < 0 ? 0 : off;
+            const int rA = (int)fd_div(fL, (uint32_t)e0);                // local row of the first inside element
+            const int endA = (rA + 1) * L;
+            const bool hasB = off + 3 >= endA && endA < span;            // the float4 reaches into the next row of this block
+            const int64_t rowA = row0 + rA;
+            const int64_t gA = p.outer == 1 ? rowA : (int64_t)fd_mod(fG, (uint32_t)rowA);
+            const Ctx cA = O::ctx(p, gA);
+            Ctx cB = cA;
+            if (hasB) cB = O::ctx(p, p.outer == 1 ? rowA + 1 : (gA + 1 == p.G ? 0 : gA + 1));
+            const int64_t i0 = (w0 + j) * 4;
+            const bool inB1 = off + 1 >= endA, inB2 = off + 2 >= endA, inB3 = off + 3 >= endA;      // element 0 is never in B
+            const bool v0 = off >= 0 && off < span, v1 = off + 1 >= 0 && off + 1 < span, v2 = off + 2 >= 0 && off + 2 < span,
+                       v3 = off + 3 < span;                              // off + 3 >= 0 always
+            const bool full = v0 && v3;
+            if (__builtin_expect(full || (cA.fast != 0 && cB.fast != 0 && lam_ok), 1)) {
+                Ctx cx[4];
+                cx[0] = cA;
+                cx[1] = ctx_select(inB1, cB, cA);
+                cx[2] = ctx_select(inB2, cB, cA);
+                cx[3] = ctx_select(inB3, cB, cA);
+                float4 xx = x[u], dd = d[u];
+                if (!full) {                                             // outside the block's span: neutral elements (see k_row_win)
+                    const float dn = __builtin_inff();
+                    if (!v0) { xx.x = 0.5f * cx[0].s; dd.x = dn; }
+                    if (!v1) { xx.y = 0.5f * cx[1].s; dd.y = dn; }
+                    if (!v2) { xx.z = 0.5f * cx[2].s; dd.z = dn; }
+                    if (!v3) { xx.w = 0.5f * cx[3].s; dd.w = dn; }
+                }
+                Acc ac[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ac[k] = O::template init<Acc>();
+                const float4 r = O::elem4c(p, cx, i0, xx, dd, ac);
+                const Acc z = O::template init<Acc>();
+                aA = ac[0];
+                acc_merge_std(aA, inB1 ? z : ac[1]);
+                acc_merge_std(aA, inB2 ? z : ac[2]);
+                acc_merge_std(aA, inB3 ? z : ac[3]);
+                acc_merge_std(aB, inB1 ? ac[1] : z);
+                acc_merge_std(aB, inB2 ? ac[2] : z);
+                acc_merge_std(aB, inB3 ? ac[3] : z);
+                if (O::kStore) {
+                    if (__builtin_expect(full, 1)) {
+                        store4<NT>(p.out + i0, r);
+                    } else {                                             // neighbouring blocks own the other elements
+                        if (v0) p.out[i0 + 0] = r.x;
+                        if (v1) p.out[i0 + 1] = r.y;
+                        if (v2) p.out[i0 + 2] = r.z;
+                        if (v3) p.out[i0 + 3] = r.w;
+                    }
+                }
+            } else {                                                     // a scale outside the exact-division window at a block edge
+#pragma clang loop unroll(disable)
+                for (int k = 0; k < 4; ++k) {
+                    const int e = off + k;
+                    const float xv = k == 0 ? x[u].x : (k == 1 ? x[u].y : (k == 2 ? x[u].z : x[u].w));
+                    const float dv = k == 0 ? d[u].x : (k == 1 ? d[u].y : (k == 2 ? d[u].z : d[u].w));
+                    if (e >= 0 && e < span) {
+                        const bool inB = e >= endA;
+                        const Ctx c = ctx_select(inB, cB, cA);
+                        Acc one = O::template init<Acc>();
+                        const float r = O::elem(p, c, i0 + k, xv, O::kDy ? dv : 0.f, one);
+                        if (inB) acc_merge_std(aB, one);
+                        else acc_merge_std(aA, one);
+                        if (O::kStore) p.out[i0 + k] = r;
+                    }
+                }
+            }
+        }
+        if (O::kReduce) {
+            lds[j * 2 + 0] = aA;
+            lds[j * 2 + 1] = aB;
+        }
+    }
+    if (O::kReduce) {
+        __syncthreads();
+        for (int r = t; r < rows; r += kBlock) {
+            const int e_lo = r * L;
+            const int j_lo = (ph + e_lo) >> 2, j_hi = (ph + e_lo + L - 1) >> 2;
+            // the first float4 of the row holds it as ITS first row (A) unless it begins in the previous row (then as B)
+            const bool firstB = r > 0 && j_lo * 4 - ph < e_lo;
+            Acc acc = lds[j_lo * 2 + (firstB ? 1 : 0)];
+            for (int j = j_lo + 1; j <= j_hi; ++j) acc_merge_std(acc, lds[j * 2]);
+            const int64_t row = row0 + r;
+            int64_t idx = row;                          // outer == 1: partial index == row == group
+            if (p.outer != 1) {
+                const uint32_t o = fd_div(fG, (uint32_t)row), g = (uint32_t)row - o * fG.d;
+                idx = (int64_t)g * p.outer + o;         // group-major partials (see row_small_body)
+            }
+            write_partial_t<OP>(p, idx, acc);
         }
     }
 }

@@ -150,7 +150,11 @@ STREAM2_SHAPES = [
     ((8500, 515), "rowwise"),          # 64 lanes x 3
     ((6000, 777), "rowwise"),          # 64 lanes x 4
     ((4300, 1023), "rowwise"),         # 257 float4: 64 lanes x 5
-    ((140001, 30), "rowwise"),         # 8 lanes per row; L % 4 == 2: rows start on two of the four phases only
+    ((140001, 30), "rowwise"),         # L % 4 == 2: rows start on two of the four phases only
+    # (rows of 5..64 off-grid elements run k_row_seg: one flat window per block, segmented reduction through LDS)
+    ((600001, 7), "rowwise"),          # 292 rows per block: the row walk loops
+    ((70001, 63), "rowwise"),          # 32 rows per block
+    ((3, 30000, 61), "columnwise"),    # outer > 1: the next row's group wraps around at G
     # column tiles whose rows are off the 16-byte grid (C % 4 != 0): dword-aligned float4 access, the last lane re-reads columns
     ((70000, 67), "columnwise"),       # C = 67: one column block, the last lane repeats one column
     ((33000, 130), "columnwise"),      # C % 4 == 2

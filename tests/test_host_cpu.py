@@ -253,6 +253,17 @@ def test_fast_division_sequence_is_exact_on_cpu(tmp_path):
     assert res.returncode == 0 and " 0 mismatches" in res.stdout, res.stdout + res.stderr
 
 
+def test_invariant_divisor_division_is_exact_on_cpu(tmp_path):
+    """tests/tools/check_fastdiv.cpp: csrc/lq_fastdiv.hpp (the header the flat streaming kernels take an element's group from)
+    == the CPU's `/` and `%` for 34 fixed divisors x 2 M dividends each, 2000 random divisors, and the edges of the quotient steps."""
+    import subprocess
+    exe = str(tmp_path / "check_fastdiv")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "learned_quantization_amd", "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "tools", "check_fastdiv.cpp")])
+    res = subprocess.run([exe, "2000", "2025"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and " 0 mismatches" in res.stdout, res.stdout + res.stderr
+
+
 def test_batch_abi_validation_without_gpu():
     """lq_batch_* argument checks that return before any HIP call."""
     import ctypes
