@@ -78,7 +78,11 @@ struct Plan {
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 static bool flat_cols_ok(int64_t C) { return C == 8 || C == 16 || C == 32 || C == 64; }
-static int64_t periodic_blocks(int64_t C) { return C * ((2048 + C / 2) / C); }      // ~2048 blocks, a multiple of C
+static int64_t periodic_target() {      // development knob LQ_TUNE_PER_NB: block count of the periodic column form (default 2048)
+    static const int64_t v = getenv("LQ_TUNE_PER_NB") ? atoll(getenv("LQ_TUNE_PER_NB")) : 2048;
+    return v > 0 ? v : 2048;
+}
+static int64_t periodic_blocks(int64_t C) { return C * ((periodic_target() + C / 2) / C); }      // ~2048 blocks, a multiple of C
 
 // Chunks of CH elements per row of length L.  A tail of at most CH/8 elements is folded into the previous chunk (the
 // traversal's last chunk takes whatever remains) instead of getting a block of its own.
@@ -114,7 +118,7 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
                 per4 = 1;
                 // streaming size: a block count that is a multiple of C (what the float4 grid-stride variant needs);
                 // the scalar periodic variant runs on the same geometry (trailing blocks may own no rows)
-                nby = C * ((2048 + C / 2) / C);
+                nby = periodic_blocks(C);
                 const int64_t k = 64 / C;
                 RB = ceil_div(ceil_div(outer, nby), 4 * k) * 4 * k;
             } else if (C <= 64) {
