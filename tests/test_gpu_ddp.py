@@ -152,3 +152,20 @@ def test_one_rank_rccl_penalty_injection_on_bucket_views(mode, loss):
                            "--rate", "1e-7", "--batch", "32", "--steps", "4", "--warmup", "4", "--batched", "--force-dist"] + extra)
         line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
         assert line["backend"] == "nccl" and np.isfinite(line["final_loss"])
+
+
+def test_bench_two_ranks_through_the_driver_launcher():
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` -- the launcher line the driver uses for N > 1 --
+    with both ranks on the one GPU of the box (gloo transport: RCCL needs a GPU per rank): RANK / LOCAL_RANK / WORLD_SIZE from the
+    environment, barrier + max-over-ranks timing, ONE JSON line from rank 0 whose value counts both ranks' images."""
+    import json
+    out = _run_script(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                       "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-extras"])
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 512 and line["config"]["parallelism"] == "dp2"
+    assert abs(line["value"] - 512 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+    assert line["cpu_baseline"] is None                      # timed on rank 0 at N = 1 only
