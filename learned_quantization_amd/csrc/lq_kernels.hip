@@ -386,6 +386,20 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                 return check_hip("flat forward launch") ? -1 : 1;
             }
         }
+        // every other column-mode forward (several groups inside a float4: C = 3, 5, 10, 30; inner = 2, 3, 5, 15): gathered scales
+        static const int gather_on = tune_int("LQ_TUNE_GATHER", 1);
+        if (gather_on && !(off & 1) && pl.mode == MODE_COL && !one_group && !scale4 && !scale4u && !cols_pow2 && n < 4294967296ll) {
+            const int64_t nv = n >> 2;
+            const int rem = (int)(n & 3);
+            const int64_t blocks = ceil_div(nv + (rem ? 1 : 0), 512);
+            if (blocks <= 2147483647ll) {
+#define LQ_FLATG(NT_, GM_) hipLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, p, fx, nv, rem)
+                if (p.inner == 1) { if (nt) LQ_FLATG(1, 10); else LQ_FLATG(0, 10); }
+                else { if (nt) LQ_FLATG(1, 11); else LQ_FLATG(0, 11); }
+#undef LQ_FLATG
+                return check_hip("flat forward launch") ? -1 : 1;
+            }
+        }
         if (!(off & 1) && (one_group || scale4) && !cols_pow2) {
             const int64_t nv = n >> 2;
             const int64_t blocks = ceil_div(nv, 512);

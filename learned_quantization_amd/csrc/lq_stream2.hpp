@@ -39,6 +39,8 @@ namespace lq {
 //            per thread costs more than it saves when each is used for a single element
 // ------------------------------------------------------------------------------------------
 //     8 / 9: inner == 1 and G % 4 != 0 (G >= 4): as 4 / 5 with a dword-aligned scale float4, element by element where it wraps
+//     10 / 11: any descriptor below 2^32 elements (10: inner == 1), a scale gathered per element -- the forward of the column
+//            modes whose float4s hold several groups (C = 3, 5, 10, 30; inner = 2, 3, 5, 15)
 //     6 / 7: long rows that do not start on 16-byte lines (row mode with inner % 4 != 0, e.g. rows of 4100 or 4099 elements):
 //            the row-stream kernel would start every block in the middle of a 128-byte line (each 1 KB wave access then touches
 //            9 lines instead of 8: K1 5.4-5.9 TB/s); as a flat stream every access is line-aligned, a float4 has one group
@@ -87,6 +89,31 @@ __global__ __launch_bounds__(BS) void k_flat_fwd(Params p, FlatIdx fx, int64_t n
                 sv.y = p.s[c + 1 < p.G ? c + 1 : c + 1 - p.G];
                 sv.z = p.s[c + 2 < p.G ? c + 2 : c + 2 - p.G];
                 sv.w = p.s[c + 3 < p.G ? c + 3 : c + 3 - p.G];
+            }
+            float4 q;
+            q.x = floorf(x.x / sv.x); q.y = floorf(x.y / sv.y); q.z = floorf(x.z / sv.z); q.w = floorf(x.w / sv.w);   // custom_layers.py:56-59
+            o.x = q.x * sv.x; o.y = q.y * sv.y; o.z = q.z * sv.z; o.w = q.w * sv.w;                                   // :60
+            if (p.q) {
+                store_q(p.q, p.q_dtype, i + 0, q.x);
+                store_q(p.q, p.q_dtype, i + 1, q.y);
+                store_q(p.q, p.q_dtype, i + 2, q.z);
+                store_q(p.q, p.q_dtype, i + 3, q.w);
+            }
+        } else if (GM == 10 || GM == 11) {
+            // ANY descriptor below 2^32 elements: the group of each element from its flat index (invariant-divisor arithmetic,
+            // ~12 VALU per element), its scale gathered from the (cache-resident) scale vector, the IEEE `/`.  GM 10: inner == 1.
+            const uint32_t iu = (uint32_t)i;
+            float4 sv;
+            if (GM == 10) {
+                sv.x = p.s[fd_mod(fx.G, iu)];
+                sv.y = p.s[fd_mod(fx.G, iu + 1)];
+                sv.z = p.s[fd_mod(fx.G, iu + 2)];
+                sv.w = p.s[fd_mod(fx.G, iu + 3)];
+            } else {
+                sv.x = p.s[fd_mod(fx.G, fd_div(fx.inner, iu))];
+                sv.y = p.s[fd_mod(fx.G, fd_div(fx.inner, iu + 1))];
+                sv.z = p.s[fd_mod(fx.G, fd_div(fx.inner, iu + 2))];
+                sv.w = p.s[fd_mod(fx.G, fd_div(fx.inner, iu + 3))];
             }
             float4 q;
             q.x = floorf(x.x / sv.x); q.y = floorf(x.y / sv.y); q.z = floorf(x.z / sv.z); q.w = floorf(x.w / sv.w);   // custom_layers.py:56-59
