@@ -86,15 +86,17 @@ def test_rows_longer_than_2_to_30_with_per_row_scales():
     np.testing.assert_array_equal(out[:, L - 3000:].cpu().numpy(), out_o)
 
 
-@pytest.mark.parametrize("L", [1028, 1029])
+@pytest.mark.parametrize("L", [1028, 1029, 1001])
 def test_flat_forward_beyond_2_to_32_elements(L):
     """More than 2^32 elements in rows that are not whole 128-byte lines: the line-aligned flat forward with 64-bit group
-    arithmetic (k_flat_fwd group modes 2 and 7 of csrc/lq_stream2.hpp; L = 1029: float4s straddle row ends)."""
+    arithmetic (k_flat_fwd group mode 2 of csrc/lq_stream2.hpp for L = 1028; L = 1029 keeps the row stream with its scalar head /
+    tail elements; L = 1001 < 1024: group mode 7, float4s straddle row ends) -- and, for L = 1001, the scale gradient through the
+    row-window kernel (k_row_win) whose element offsets pass 2^32."""
     import learned_quantization_amd as lq
     dev = torch.device("cuda:0")
     if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
         pytest.skip("needs ~40 GB of device memory")
-    R = 4180000
+    R = 4300000
     assert R * L > 2 ** 32
     g = torch.Generator(device=dev).manual_seed(3)
     P = torch.empty(R, L, device=dev)
@@ -110,3 +112,29 @@ def test_flat_forward_beyond_2_to_32_elements(L):
     for a in (0, (2 ** 32) // L - 2, R - 3):                                  # oracle across the 2^32 boundary and at both ends
         _, out_o = O.fq_forward(P[a:a + 3].cpu().numpy(), s[a:a + 3].cpu().numpy())
         np.testing.assert_array_equal(out[a:a + 3].cpu().numpy(), out_o)
+    if L != 1001:
+        return
+    lam = 2e-5
+    dy = torch.empty(R, L, device=dev)
+    for a in range(0, R, rows):
+        b = min(R, a + rows)
+        dy[a:b] = torch.randn(b - a, L, device=dev, generator=g) * 1e-3
+    ds, parts = lq.fq_scale_grad(P, s, dy, lam, return_parts=True)
+    out2, ds2 = lq.fq_fwd_bwd_fused(P, s, dy, lam, out=out)
+    for a in range(0, R, rows):
+        b = min(R, a + rows)
+        qr = torch.floor(P[a:b] / s[a:b])
+        outr = qr * s[a:b]
+        assert torch.equal(out2[a:b], outr), f"fused rows {a}..{b}"
+        maxq = qr.abs().amax(1)
+        assert torch.equal(parts[0, a:b].reshape(-1), maxq), f"max|q| rows {a}..{b}"
+        nz = torch.where(outr == 0, torch.full_like(outr, O.EPS_F32), outr)
+        ratio = dy[a:b].abs() / nz.abs()
+        m = ~(ratio >= lam)
+        vote = torch.where(m, -torch.tanh(lam - ratio).abs(), torch.zeros_like(ratio)).double().sum(1)
+        cnt = m.sum(1)
+        mean = torch.where(cnt == 0, torch.full_like(vote, -float(np.abs(np.tanh(np.float32(lam))))), vote / L)
+        ref = (mean * maxq.double()).float()
+        for got, name in ((ds, "split"), (ds2, "fused")):
+            torch.testing.assert_close(got[a:b].reshape(-1), ref, rtol=2e-5, atol=1e-30, msg=lambda m_: f"{name} ds rows {a}..{b}: {m_}")
+        del qr, outr, nz, ratio, m, vote
