@@ -426,6 +426,23 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     }
     if (pl.mode == MODE_COL) {
         constexpr int kUp = (OP == OP_FWD) ? 4 : 2;            // float4 per stream in flight: one stream wants 4, two streams 2
+        // K2 of C = 8, 16, 32, 64 as a one-shot stream with FOUR float4 per thread and stream: with two, nothing hid the shuffle
+        // tree and the barrier at the end of so short a wave (4.3-5.4 TB/s); with four the epilogue is paid once per 8 KB of each
+        // stream: 6.0-6.2 TB/s against 5.5-5.6 for the periodic form.  (K4 with four: 5.6-5.9 against 5.7-6.1 with two.)
+        if constexpr (OP == OP_BWD) {
+            static const int fc_k2 = tune_int("LQ_TUNE_FC_K2", 4);      // development knob: 0 = the periodic form
+            if (fc_k2 == 4 && pl.C <= 64 && pl.per4 && flat_cols_ok(pl.C) && nt && !(off & 64)) {
+                const int64_t nv = n >> 2;
+                const int64_t fb = ceil_div(nv, (int64_t)kFlatColsBlock * 4);
+                if (fb <= 2147483647ll && fb * pl.C <= pl.np) {
+                    pl.ysplit = fb;           // the finalize that follows must walk the partial layout this launch produces
+                    pl.np = fb * pl.C;
+                    pl.n1 = fb;
+                    hipLaunchKernelGGL((k_flat_cols<OP, 1, 4>), dim3((unsigned)fb), dim3(kFlatColsBlock), 0, st, p, (int)pl.C, nv);
+                    return check_hip("flat column launch") ? -1 : 1;
+                }
+            }
+        }
         if (pl.C <= 64 && pl.per4 && flat_cols_ok(pl.C) && !(off & 64) && OP != OP_BWD) {
             // C = 8, 16, 32, 64 as a flat one-shot stream: K1 and K4 (the read-only K2 is faster in the periodic form)
             const int64_t nv = n >> 2;                        // numel = outer * C is a multiple of 8

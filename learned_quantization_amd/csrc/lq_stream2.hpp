@@ -15,7 +15,7 @@
 //                     iteration i, so the vmcnt wait that covers them does not include those stores.
 //   k_col_periodic_pipe   the same pipeline for the periodic float4 form (C <= 64).
 //   k_flat_cols       C = 8, 16, 32, 64 as a flat one-shot stream with an xor-shuffle tree over the lanes that share columns
-//                     (K1 and K4; the read-only K2 is faster in the periodic form).
+//                     (K1 and K4 with two float4 per thread and stream, K2 with four).
 //   k_row_win         rows of 65..1023 elements of any alignment (scale-gradient ops): aligned float4 windows per row.
 //   k_row_seg         rows of 5..64 elements off the 16-byte grid: one flat window per block, segmented reduction through LDS.
 //   k_row_tiny        rows of <= 64 elements: U passes of rows per wave with all loads up front, DPP team reductions
@@ -403,9 +403,10 @@ __global__ __launch_bounds__(BS, (U <= 2 ? 4 : 0)) void k_col_periodic_pipe(Para
 //  leaves the wave totals in lanes 0 .. C/4-1 (fixed order: run-to-run bit-stable); one LDS hop across the block's 8 waves,
 //  merged in wave order by the first C threads: one partial per (block, column).
 //  Measured (profiles/r02/tuning_flat_cols.txt): K4 5.8-6.1 TB/s against 5.4-5.8 for the periodic form, K1 6.2-6.3 against
-//  6.1-6.2 for the scale-float4 flat form; the read-only K2 is SLOWER this way (4.3-5.4 against 5.6-5.9: nothing hides the
-//  shuffle tree and the barrier at the end of so short a wave) and keeps the periodic form, as does every other C <= 64 (a
-//  per-column select + wave-reduction variant for C <= 4 ran at 1.2-2.2 TB/s).
+//  6.1-6.2 for the scale-float4 flat form; the read-only K2 is SLOWER this way with U = 2 (4.3-5.4 against 5.6-5.9: nothing hides
+//  the shuffle tree and the barrier at the end of so short a wave) but FASTER with U = 4 (6.0-6.2 against 5.5-5.6:
+//  profiles/r02/offgrid/flat_cols_k2_four_float4.txt).  Every other C <= 64 keeps the periodic form (a per-column select +
+//  wave-reduction variant for C <= 4 ran at 1.2-2.2 TB/s).
 // ------------------------------------------------------------------------------------------
 constexpr int kFlatColsBlock = 512;
 
