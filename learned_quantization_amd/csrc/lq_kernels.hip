@@ -318,9 +318,10 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         if constexpr (OP == OP_FWD) {
             static const int off_rb = tune_int("LQ_TUNE_S2", 0);
             const int64_t nn = p.outer * p.G * p.inner;
-            if (!(off_rb & 256) && p.G > 1 && (pl.L % 32 != 0 || (off_rb & 4096)) && aligned(p.P, 16) && aligned(p.out, 16)) {
-                // rows that are not a whole number of 128-byte lines: one group per float4 when L % 4 == 0 (group mode 0 / 2),
-                // else a float4 may straddle a row end (6 / 7)
+            const bool poor_fill = (double)pl.L / (double)(pl.nc * pl.CH) < 0.95;      // e.g. rows of 1600 = 1024 + 576: 5.65 -> 6.3 TB/s
+            if (!(off_rb & 256) && p.G > 1 && (pl.L % 32 != 0 || poor_fill || (off_rb & 4096)) && aligned(p.P, 16) && aligned(p.out, 16)) {
+                // rows that are not a whole number of 128-byte lines, or that fill their chunks poorly: one group per float4 when
+                // L % 4 == 0 (group mode 0 / 2), else a float4 may straddle a row end (6 / 7)
                 const int64_t nv = nn >> 2;
                 const int rem = (int)(nn & 3);
                 const int64_t blocks = ceil_div(nv + (rem ? 1 : 0), 512);
@@ -331,9 +332,10 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                     if (pl.L % 4 == 0) {
                         if (ntb) { if (wide) LQ_FLATR(1, 2); else LQ_FLATR(1, 0); }
                         else { if (wide) LQ_FLATR(0, 2); else LQ_FLATR(0, 0); }
-                    } else if (!(off_rb & 512)) {
+                    } else if (!(off_rb & 512) && (double)pl.L / (double)(pl.nc * pl.CH) >= 0.8) {
                         // long rows with L % 4 != 0 keep the row stream (TAIL instantiation): K1 5.8-6.0 TB/s on rows of 1025,
                         // 2047, 4099, 50177 against 5.4-5.9 for the straddling flat form (development knob 512 selects the latter)
+                        // -- unless their chunks are poorly filled (rows of 1225 = 1024 + 201 elements: 4.3 TB/s)
                         return 0;
                     } else {
                         if (ntb) { if (wide) LQ_FLATR(1, 7); else LQ_FLATR(1, 6); }
@@ -341,6 +343,33 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                     }
 #undef LQ_FLATR
                     return check_hip("flat forward launch") ? -1 : 1;
+                }
+            }
+        } else {
+            // Rows of 1153..1533 elements are two 1024-chunks, the second one 13-50 % full (35 x 35 planes: 1225 = 1024 + 201) --
+            // too few bytes in flight per resident thread: K2 / K4 4.0 / 3.9 TB/s.  One wave per row through the row-window
+            // kernel instead (5 or 6 float4 per lane: 80-100 % of the lanes carry data); partials as in the row-small mode.
+            static const int off_rb = tune_int("LQ_TUNE_S2", 0);
+            const int nwin = (int)(pl.L % 4 ? (pl.L + 6) / 4 : pl.L / 4);
+            const bool al = aligned(p.P, 16) && aligned(p.dy, 16) && (!O::kStore || aligned(p.out, 16));
+            if (!(off_rb & 128) && pl.bs == 256 && pl.nc == 2 && nwin <= 384 && al && !p.direct && pl.R < 4294967296ll) {
+                const int64_t blocks = ceil_div(pl.R, (int64_t)kWavesPerBlock);
+                if (blocks <= 2147483647ll) {
+                    const int64_t n = p.outer * p.G * p.inner;
+                    const bool ntb = numel * 4.0 >= (double)kNtBytes;
+                    const FastDiv fG = make_fastdiv((uint32_t)p.G);
+                    const int64_t f_outer = pl.R / p.G;
+                    pl.nc = 1;                 // the finalize that follows must walk the partial layout this launch produces:
+                    pl.np = pl.R;              // one partial per row, group-major (g * outer + o), as in the row-small mode
+                    pl.gstride = f_outer;
+                    pl.n1 = f_outer;
+                    pl.stride1 = 1;
+                    pl.n2 = 1;
+#define LQ_WINB(NT_, V_) hipLaunchKernelGGL((k_row_win<OP, NT_, 6, V_, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, fG, pl.R, (int)pl.L, n)
+                    if (nwin <= 320) { if (ntb) LQ_WINB(1, 5); else LQ_WINB(0, 5); }
+                    else { if (ntb) LQ_WINB(1, 6); else LQ_WINB(0, 6); }
+#undef LQ_WINB
+                    return check_hip("row-window launch") ? -1 : 1;
                 }
             }
         }

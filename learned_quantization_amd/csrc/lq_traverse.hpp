@@ -104,8 +104,8 @@ __device__ __forceinline__ void row_stream_body(const Params& p, int64_t L, int6
         const bool fold = TAIL && len4 > BS * U;          // block-uniform
         const int je = BS * U + (int)threadIdx.x;
         float4 xe = make_float4(0.f, 0.f, 0.f, 0.f), de = xe;
-        if (__builtin_expect(fold, 0)) {
-            const int64_t ie0 = vbase + (int64_t)(je < len4 ? je : 0) * 4;
+        if (__builtin_expect(fold && je < len4, 0)) {     // only the lanes that own a folded float4 (a few of wave 0) issue these loads
+            const int64_t ie0 = vbase + (int64_t)je * 4;
             xe = load4<NT>(p.P + ie0);
             de = xe;
             if (O::kDy) de = load4<NT>(p.dy + ie0);

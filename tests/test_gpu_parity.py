@@ -155,6 +155,11 @@ STREAM2_SHAPES = [
     ((600001, 7), "rowwise"),          # 292 rows per block: the row walk loops
     ((70001, 63), "rowwise"),          # 32 rows per block
     ((3, 30000, 61), "columnwise"),    # outer > 1: the next row's group wraps around at G
+    # rows of 1153..1533 elements (two poorly filled 1024-chunks in the row stream): one wave per row, 5 or 6 float4 per lane
+    ((3500, 1225), "rowwise"),         # 35 x 35 planes: off the 16-byte grid, flat straddling forward
+    ((3300, 1300), "rowwise"),         # aligned, 325 float4: 6 per lane
+    ((2900, 1500), "rowwise"),         # 375 float4
+    ((3, 1200, 1229), "columnwise"),   # outer > 1: group-major partials replace the row-stream layout
     # column tiles whose rows are off the 16-byte grid (C % 4 != 0): dword-aligned float4 access, the last lane re-reads columns
     ((70000, 67), "columnwise"),       # C = 67: one column block, the last lane repeats one column
     ((33000, 130), "columnwise"),      # C % 4 == 2
