@@ -528,6 +528,20 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
             else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
             return check_hip("periodic column launch") ? -1 : 1;
         }
+        // 256 < C <= 512 whose second column block is mostly empty (C = 320: 16 of 64 lanes in half the blocks, K2 / K4 4.7 / 4.5 TB/s)
+        // or whose rows start inside a 128-byte line: the periodic form with 512-thread blocks (its LDS combine needs C <= block
+        // size): C = 300: 4.2 / 4.0 -> 5.5 / 5.4; 320: -> 5.6 / 5.5; 450: 4.8 / 4.5 -> 5.4 / 5.4; 500: 5.3 / 4.9 -> 5.5 / 5.6
+        if (nt && pl.C > 256 && pl.C <= 512 && pl.C <= per_cmax * 2 && ((double)pl.C / 512.0 < 0.8 || pl.C % 32 != 0)) {
+            const int64_t nb = pl.C * ((1024 + pl.C / 2) / pl.C);          // ~1024 blocks of 512 threads, a multiple of C
+            if (nb * pl.C <= pl.np) {
+                pl.ysplit = nb;               // the finalize that follows must walk the partial layout this launch produces
+                pl.np = nb * pl.C;
+                pl.n1 = nb;
+                if (OP == OP_FUSED) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1, 512>), dim3((unsigned)nb), dim3(512), 0, st, p, (int)pl.C, nb);
+                else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 2, 512>), dim3((unsigned)nb), dim3(512), 0, st, p, (int)pl.C, nb);
+                return check_hip("periodic column launch") ? -1 : 1;
+            }
+        }
         const bool ua = pl.C % 4 != 0;
         if ((off & 2) || (ua && (off & 2048))) return 0;
         const int64_t nbx = ceil_div(pl.C, 256);

@@ -172,6 +172,9 @@ STREAM2_SHAPES = [
     ((42001, 33, 3), "columnwise"),    # C = 99 with inner = 3, numel % 4 == 3
     ((21000, 200), "columnwise"),      # C = 200 (C % 32 != 0)
     ((21900, 192), "columnwise"),      # C = 192 keeps the column tile (3 full lines per row)
+    # (at >= 64 MiB) 256 < C <= 512 with a mostly empty second column block or rows off the 128-byte grid: periodic form, 512-thread blocks
+    ((56000, 320), "columnwise"),      # 17.9 M elements: nontemporal size
+    ((38001, 450), "columnwise"),      # C % 4 == 2, numel % 4 == 2
 ]
 
 
