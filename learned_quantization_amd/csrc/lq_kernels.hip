@@ -352,7 +352,11 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
             static const int off_rb = tune_int("LQ_TUNE_S2", 0);
             const int nwin = (int)(pl.L % 4 ? (pl.L + 6) / 4 : pl.L / 4);
             const bool al = aligned(p.P, 16) && aligned(p.dy, 16) && (!O::kStore || aligned(p.out, 16));
-            if (!(off_rb & 128) && pl.bs == 256 && pl.nc == 2 && nwin <= 384 && al && !p.direct && pl.R < 4294967296ll) {
+            // (rows of 1534..2047 elements: two chunks that fill >= 75 % -- the row stream is as good or better (1800: K2 / K4 6.4 / 5.8
+            // against 6.0 / 5.5 with 8 float4 per lane) unless the rows are off the 16-byte grid (1535, 1537: 5.0 / 4.7 -> 6.1 / 5.6))
+            static const int win_max = tune_int("LQ_TUNE_WIN_MAX", 384);      // development knob: widest window (float4) for rows ON the grid
+            const bool wide_ok = pl.L % 4 != 0 && (double)pl.L / 2048.0 < 0.95;
+            if (!(off_rb & 128) && pl.bs == 256 && pl.nc == 2 && (nwin <= win_max || wide_ok) && nwin <= 512 && al && !p.direct && pl.R < 4294967296ll) {
                 const int64_t blocks = ceil_div(pl.R, (int64_t)kWavesPerBlock);
                 if (blocks <= 2147483647ll) {
                     const int64_t n = p.outer * p.G * p.inner;
@@ -367,7 +371,9 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                     pl.n2 = 1;
 #define LQ_WINB(NT_, V_) hipLaunchKernelGGL((k_row_win<OP, NT_, 6, V_, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, fG, pl.R, (int)pl.L, n)
                     if (nwin <= 320) { if (ntb) LQ_WINB(1, 5); else LQ_WINB(0, 5); }
-                    else { if (ntb) LQ_WINB(1, 6); else LQ_WINB(0, 6); }
+                    else if (nwin <= 384) { if (ntb) LQ_WINB(1, 6); else LQ_WINB(0, 6); }
+                    else if (nwin <= 448) { if (ntb) LQ_WINB(1, 7); else LQ_WINB(0, 7); }
+                    else { if (ntb) LQ_WINB(1, 8); else LQ_WINB(0, 8); }
 #undef LQ_WINB
                     return check_hip("row-window launch") ? -1 : 1;
                 }

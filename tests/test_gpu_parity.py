@@ -160,6 +160,8 @@ STREAM2_SHAPES = [
     ((3300, 1300), "rowwise"),         # aligned, 325 float4: 6 per lane
     ((2900, 1500), "rowwise"),         # 375 float4
     ((3, 1200, 1229), "columnwise"),   # outer > 1: group-major partials replace the row-stream layout
+    ((2800, 1537), "rowwise"),         # off the grid up to 1945 elements: 7 or 8 float4 per lane
+    ((2300, 1901), "rowwise"),
     # column tiles whose rows are off the 16-byte grid (C % 4 != 0): dword-aligned float4 access, the last lane re-reads columns
     ((70000, 67), "columnwise"),       # C = 67: one column block, the last lane repeats one column
     ((33000, 130), "columnwise"),      # C % 4 == 2
