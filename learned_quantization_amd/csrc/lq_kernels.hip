@@ -78,6 +78,10 @@ struct Plan {
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 static bool flat_cols_ok(int64_t C) { return C == 8 || C == 16 || C == 32 || C == 64; }
+static int64_t colx_max_inner() {        // development knob LQ_TUNE_COLX_INNER: rows shorter than this may run in column mode (see make_plan)
+    static const int64_t v = getenv("LQ_TUNE_COLX_INNER") ? atoll(getenv("LQ_TUNE_COLX_INNER")) : 200;
+    return v;
+}
 static int64_t periodic_target() {      // development knob LQ_TUNE_PER_NB: block count of the periodic column form (default 2048)
     static const int64_t v = getenv("LQ_TUNE_PER_NB") ? atoll(getenv("LQ_TUNE_PER_NB")) : 2048;
     return v > 0 ? v : 2048;
@@ -107,7 +111,14 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
         R = outer * G;
         L = inner;
         f_outer = outer;
-        if (inner < 16 && outer > 1) {
+        // Short rows that come in many layers (outer >= 32: per-channel scales of NCHW activations with small planes, e.g.
+        // (256, 2048, 7 x 7)) are instruction-bound as rows -- per-row context, team reduction and emit every 100-400 bytes --
+        // but as the matrix [outer][G * inner] a lane keeps its four columns, contexts and accumulators across all layers:
+        // column mode for them too, at streaming size and when the matrix rows are whole 128-byte lines.
+        static const int colx = getenv("LQ_TUNE_COLX") ? atoi(getenv("LQ_TUNE_COLX")) : 1;      // development knob: 0 = rows
+        const bool short_rows_many_layers = colx && inner >= 16 && inner < colx_max_inner() && outer >= 32 && (G * inner) % 32 == 0 &&
+                                            G * inner > 64 && (double)N >= (double)kPeriodic4Min && !(inner % 4 == 0 && (inner & (inner - 1)) == 0);
+        if ((inner < 16 && outer > 1) || short_rows_many_layers) {
             // column mode unless thread-per-row yields fewer partials
             const int64_t C = G * inner;
             // rows per block: ~16 K elements per block for narrow matrices, 128 rows for wide ones
@@ -140,10 +151,14 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
                 // count, so the workspace bound holds for both
                 // (C % 4 != 0: the same tile with dword-aligned float4 access, k_col_pipe<..., UA = 1>)
                 if ((double)outer * (double)C >= (double)kPeriodic4Min) RB = kColRbFused;
+                // short rows in many layers (see above): one partial per column and 128 layers keeps the partial count near the
+                // row count (a partial per column and 48 layers would be 5-10 % of the traffic for rows of 100+ elements)
+                // -- only when 48 layers per block would not fit the partial budget below (K4 prefers 48: 7 x 7 planes 5.4 against 5.2)
+                if (short_rows_many_layers && ceil_div(outer, kColRbFused) * C > 2 * R) RB = kColRbBwd;
             }
             if (RB > outer) RB = outer;
             if (!nby) nby = ceil_div(outer, RB);
-            if (nby * C <= R) {
+            if (nby * C <= R || (short_rows_many_layers && nby * C <= 2 * R)) {
                 col = true;
                 pl.mode = MODE_COL;
                 pl.C = C;

@@ -133,11 +133,19 @@ def difference_term_grads(P, s, c, outer, G, inner, with_dP_abs=False):
     """d(c * mean |P - P/s|): returns (dP, ds, ds_abs) [, dP_abs].  dP_i = g_i - g_i/s is itself a sum of TWO signed terms
     (the gradient through P and the one through P/s, which autodiff adds): they cancel when s is near 1, so its yardstick
     is |g_i| + |g_i/s|, not |dP_i|."""
-    P = np.asarray(P, np.float64).reshape(-1)
-    s = np.asarray(s, np.float64).reshape(-1)
+    P32 = np.asarray(P, np.float32).reshape(-1)
+    s32 = np.asarray(s, np.float32).reshape(-1)
+    P = P32.astype(np.float64)
+    s = s32.astype(np.float64)
     gid = group_ids(outer, G, inner)
     pq = P / s[gid]
-    g = np.sign(P - pq) * (float(c) / P.size)
+    # tf.sign of the float32 residual (custom_loss_functions.py:172-176 runs in float32): WHICH sign an element gets -- and
+    # whether it is exactly zero, which happens for s within an ulp of 1, where fl(P / s) == P -- is the reference's float32
+    # decision, as the MaxBin tie split is; the magnitudes around it are float64.  (Seen in a soak: 3 of 1580 elements with a
+    # zero float32 residual, gradient 0 in float32 and in the kernel, 1.8e-7 with a float64 sign.)
+    with np.errstate(all="ignore"):
+        sgn = np.sign(P32 - P32 / s32[gid]).astype(np.float64)
+    g = sgn * (float(c) / P.size)
     dP = g - g / s[gid]
     terms = g * pq / s[gid]
     ds = np.bincount(gid, weights=terms, minlength=G)

@@ -162,6 +162,10 @@ STREAM2_SHAPES = [
     ((3, 1200, 1229), "columnwise"),   # outer > 1: group-major partials replace the row-stream layout
     ((2800, 1537), "rowwise"),         # off the grid up to 1945 elements: 7 or 8 float4 per lane
     ((2300, 1901), "rowwise"),
+    # short rows in many layers (outer >= 32, G * inner a whole number of 128-byte lines): column mode with inner >= 16
+    ((48, 2048, 49), "columnwise"),    # 7 x 7 planes: 4.8 M elements, 48 layers per block
+    ((40, 1024, 132), "columnwise"),   # rows of 132: 128 layers per block (one partial per column)
+    ((64, 4096, 20), "columnwise"),    # aligned short rows, one group per float4 in the forward
     # column tiles whose rows are off the 16-byte grid (C % 4 != 0): dword-aligned float4 access, the last lane re-reads columns
     ((70000, 67), "columnwise"),       # C = 67: one column block, the last lane repeats one column
     ((33000, 130), "columnwise"),      # C % 4 == 2
