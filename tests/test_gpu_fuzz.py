@@ -253,9 +253,14 @@ def test_int32_view_saturates(dev):
 def _rand_streaming_case(rng):
     """Random descriptor of 4.2-6 M elements that lands in one of the streaming-size forms (csrc/lq_stream2.hpp): column tile
     (any C % 4 == 0 > 64, ragged row counts), periodic columns (C <= 64, any C), tiny rows (L in 8..64, L % 4 == 0), rows of
-    68..1020 (flat forward), ragged long rows (TAIL instantiation of the row stream), rows of 5..1023 with L % 4 != 0."""
-    kind = int(rng.integers(0, 6))
+    68..1020 (flat forward), ragged long rows (TAIL instantiation of the row stream), rows of 5..1023 with L % 4 != 0, short rows in 32+ layers."""
+    kind = int(rng.integers(0, 7))
     n = int(rng.integers(4_200_000, 6_000_000))
+    if kind == 6:                                   # short rows in many layers: column mode with 16 <= inner < 200
+        inner = int(rng.integers(17, 200))
+        outer = int(rng.integers(32, 80))
+        G = max(32, (n // (outer * inner)) // 32 * 32)        # G * inner: whole 128-byte lines
+        return (outer, G, inner), "columnwise"
     if kind == 5:                                   # rows of 5..1023 elements off the 16-byte grid: straddling flat forward + row windows
         L = int(rng.integers(5, 65)) if rng.integers(0, 2) else int(rng.integers(5, 1024))      # half of them short rows
         L += 1 if L % 4 == 0 else 0
