@@ -584,9 +584,13 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         static const int pipe_f = tune_int("LQ_TUNE_PIPE_FWD", 28);
         const int pipe = (OP == OP_FWD) ? pipe_f : pipe_r;
 #define LQ_PIPE(NT_, U_, NW_) hipLaunchKernelGGL((k_col_pipe<OP, NT_, U_, NW_>), dim3((unsigned)blocks), dim3(NW_ * 64), 0, st, p, pl.C, pl.rps, nbx)
+        static const int xcd_remap = tune_int("LQ_TUNE_XCD", 1);      // development knob: 0 = natural block order for C % 32 != 0
         if (ua) {
             if (nt) hipLaunchKernelGGL((k_col_pipe<OP, 1, 2, 8, 1>), dim3((unsigned)blocks), dim3(512), 0, st, p, pl.C, pl.rps, nbx);
             else hipLaunchKernelGGL((k_col_pipe<OP, 0, 2, 8, 1>), dim3((unsigned)blocks), dim3(512), 0, st, p, pl.C, pl.rps, nbx);
+        } else if (OP == OP_BWD && nt && pl.C % 32 != 0 && nbx > 1 && xcd_remap && pipe == 28) {
+            // rows that are not whole lines: neighbouring column blocks share a line -- keep them on one XCD (lq_stream2.hpp)
+            hipLaunchKernelGGL((k_col_pipe<OP, 1, 2, 8, 2>), dim3((unsigned)blocks), dim3(512), 0, st, p, pl.C, pl.rps, nbx);
         } else if (nt) {
             if (pipe == 14) LQ_PIPE(1, 1, 4); else if (pipe == 44) LQ_PIPE(1, 4, 4); else if (pipe == 28) LQ_PIPE(1, 2, 8);
             else if (pipe == 18) LQ_PIPE(1, 1, 8); else if (pipe == 48) LQ_PIPE(1, 4, 8); else if (pipe == 24) LQ_PIPE(1, 2, 4);

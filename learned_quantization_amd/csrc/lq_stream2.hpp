@@ -196,15 +196,23 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
     __shared__ Acc lds[O::kReduce ? NW * 256 : 1];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t b = blockIdx.x;
+    // Rows that are not whole 128-byte lines (C % 32 != 0): the first / last line of a block's 1 KB row segment is shared with the
+    // neighbouring column block.  Consecutive block indices go to consecutive XCDs (separate L2s), so each of the two fetches
+    // that line from the fabric; remapped so that one XCD owns a contiguous range of tiles, neighbours share an L2.
+    int64_t b = blockIdx.x;
+    if (UA >= 1 && OP == OP_BWD) {      // measured: the read-only K2 gains 3-5 % (C = 1000, 2000, 3000), the storing kernels LOSE 3-7 %
+        const int64_t nb = gridDim.x, q = nb >> 3, r = nb & 7;
+        const int64_t xcd = b & 7, slot = b >> 3;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
     const int64_t by = b / nbx, bx = b - by * nbx;
     const int64_t col0n = (bx * 64 + lane) * 4;
     const bool active = col0n < C;
-    // UA = 0: C % 4 == 0, a float4 never straddles a row end.  UA = 1 (any C >= 4): rows start on any 4-byte phase
+    // UA = 0 / 2: C % 4 == 0, a float4 never straddles a row end (2: with the XCD remap above).  UA = 1 (any C >= 4): rows start on any 4-byte phase
     // (dword-aligned float4 access), and the lane whose float4 would cross the row end takes the LAST four columns instead:
     // its first `kdup` elements repeat the previous lane's -- same inputs, same outputs (the stores write identical
     // values), and their accumulators are simply not emitted.
-    const int64_t col0 = (UA && col0n + 4 > C) ? C - 4 : col0n;
+    const int64_t col0 = (UA == 1 && col0n + 4 > C) ? C - 4 : col0n;
     const int kdup = (int)(col0n - col0);
     const int64_t r0 = by * RB;
     const int64_t r1 = (r0 + RB < p.outer) ? r0 + RB : p.outer;
@@ -220,9 +228,9 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
         if (groups > 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                xa[u] = load4x<NT, UA>(p.P + i0 + u * step);
+                xa[u] = load4x<NT, (UA == 1)>(p.P + i0 + u * step);
                 da[u] = xa[u];
-                if (O::kDy) da[u] = load4x<NT, UA>(p.dy + i0 + u * step);
+                if (O::kDy) da[u] = load4x<NT, (UA == 1)>(p.dy + i0 + u * step);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -241,9 +249,9 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
                 const int64_t in0 = i0 + U * step;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    xn[u] = load4x<NT, UA>(p.P + in0 + u * step);
+                    xn[u] = load4x<NT, (UA == 1)>(p.P + in0 + u * step);
                     dn[u] = xn[u];
-                    if (O::kDy) dn[u] = load4x<NT, UA>(p.dy + in0 + u * step);
+                    if (O::kDy) dn[u] = load4x<NT, (UA == 1)>(p.dy + in0 + u * step);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                // the next group's loads stay ahead of this phase's stores
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
             for (int u = 0; u < U; ++u) {
                 const int64_t i = i0 + u * step;
                 const float4 ov = O::elem4c(p, ctx, i, xc[u], dc[u], acc);
-                if (O::kStore) store4x<NT, UA>(p.out + i, ov);
+                if (O::kStore) store4x<NT, (UA == 1)>(p.out + i, ov);
             }
             ++g;
             i0 += U * step;
@@ -264,11 +272,11 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
             }
         }
         for (int t = groups * U; t < cnt; ++t) {              // at most U - 1 leftover rows
-            const float4 x = load4x<NT, UA>(p.P + i0);
+            const float4 x = load4x<NT, (UA == 1)>(p.P + i0);
             float4 d = x;
-            if (O::kDy) d = load4x<NT, UA>(p.dy + i0);
+            if (O::kDy) d = load4x<NT, (UA == 1)>(p.dy + i0);
             const float4 ov = O::elem4c(p, ctx, i0, x, d, acc);
-            if (O::kStore) store4x<NT, UA>(p.out + i0, ov);
+            if (O::kStore) store4x<NT, (UA == 1)>(p.out + i0, ov);
             i0 += step;
         }
     }
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(NW * 64) void k_col_pipe(Params p, int64_t C, int64
                 Acc r = lds[lane * 4 + k];
 #pragma unroll
                 for (int ww = 1; ww < NW; ++ww) O::merge(r, lds[ww * 256 + lane * 4 + k]);   // fixed wave order
-                if (!UA || k >= kdup) write_partial_t<OP>(p, by * C + col0 + k, r);
+                if (UA != 1 || k >= kdup) write_partial_t<OP>(p, by * C + col0 + k, r);
             }
         }
     }
