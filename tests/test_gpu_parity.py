@@ -480,3 +480,46 @@ def test_profile_events_stamp_the_kernel_itself(dev):
     assert lib.lq_fq_forward(x.data_ptr(), s.data_ptr(), out.data_ptr(), None, 0, 256, 3, 50176, None) == 0     # hook off
     torch.cuda.synchronize()
     assert abs(a.elapsed_time(b)) < 0.03          # the two records were back to back: nothing stamped them again
+
+
+MISALIGNED_STREAMING = [
+    ((48, 2048, 49), "columnwise"),    # column mode with inner = 49 (short rows in many layers): scalar column kernel, any inner
+    ((4200, 1001), "rowwise"),         # rows off the grid: round-1 row-small kernel
+    ((4200, 1001), "columnwise"),      # 1001 columns: scalar column tile on the 48-row geometry
+    ((3500, 1225), "rowwise"),         # rows of 1225: row stream with two chunks (the one-wave-per-row form needs aligned bases)
+    ((42000, 100), "columnwise"),      # C = 100: the periodic form's workspace bound, scalar tile
+    ((1100, 4100), "rowwise"),         # ragged long rows, scalar row stream
+]
+
+
+@pytest.mark.parametrize("shape,orient", MISALIGNED_STREAMING)
+def test_streaming_size_bases_off_the_16_byte_grid(shape, orient, dev):
+    """Streaming-size tensors whose base pointers are 4 bytes off the 16-byte grid: every round-2 form requires aligned bases and
+    must hand over to the round-1 kernels ON THE PLAN GEOMETRY OF ROUND 2 (rows per block, column mode for short rows in many
+    layers, workspace bounds) -- same results, bit for bit in q / out / max|q|."""
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(stable_seed(shape, orient, "misaligned"))
+    n = int(np.prod(shape))
+    Pn = rng.normal(0, 0.05, size=shape).astype(np.float32)
+    dn = (rng.normal(0, 1, size=shape) * 10.0 ** rng.uniform(-9, -2, size=shape)).astype(np.float32)
+    sn = rng.uniform(1e-3, 3e-2, size=O.scale_shape(shape, orient)).astype(np.float32)
+    base_p = torch.empty(n + 1, device=dev)
+    base_d = torch.empty(n + 1, device=dev)
+    base_o = torch.empty(n + 1, device=dev)
+    base_p[1:].copy_(torch.from_numpy(Pn.reshape(-1)))
+    base_d[1:].copy_(torch.from_numpy(dn.reshape(-1)))
+    P, dy, out_buf = base_p[1:].view(shape), base_d[1:].view(shape), base_o[1:].view(shape)
+    assert P.data_ptr() % 16 == 4 and P.is_contiguous()
+    s = _t(sn, dev)
+    lam = 3e-2
+    q_o, out_o = O.fq_forward(Pn, sn)
+    _, ds_o, im = O.nq_backward(Pn, sn, lam, dn, return_intermediates=True)
+    out, q = lq.fq_forward(P, s, q_dtype=torch.int32)
+    np.testing.assert_array_equal(out.cpu().numpy(), out_o)
+    np.testing.assert_array_equal(q.cpu().numpy(), q_o.astype(np.int32))
+    ds, parts = lq.fq_scale_grad(P, s, dy, lam, return_parts=True)
+    np.testing.assert_array_equal(parts[0].cpu().numpy(), np.asarray(im["maxvalue"], np.float32).reshape(-1))
+    np.testing.assert_allclose(ds.cpu().numpy(), ds_o, rtol=1e-5, atol=1e-30)
+    out2, ds2 = lq.fq_fwd_bwd_fused(P, s, dy, lam, out=out_buf)
+    np.testing.assert_array_equal(out2.cpu().numpy(), out_o)
+    np.testing.assert_allclose(ds2.cpu().numpy(), ds_o, rtol=1e-5, atol=1e-30)
