@@ -314,7 +314,7 @@ def main():
     mean_us = lambda prs: sum(a.elapsed_time(b) for a, b in prs[4:]) / len(prs[4:]) * 1e3      # noqa: E731
     t_k1, t_k2, t_k4 = mean_us(e1), mean_us(e2), mean_us(e4)
     kernels = {}
-    for name, t_us, nbytes in (("K1 k_row_stream<OP_FWD> (lq_fq_forward)", t_k1, BYTES_FWD),
+    for name, t_us, nbytes in (("K1 k_flat_fwd<OP_FWD> (lq_fq_forward)", t_k1, BYTES_FWD),
                                ("K2 k_row_stream<OP_BWD> (lq_fq_scale_grad, traversal)", t_k2, BYTES_BWD),
                                ("K4 k_row_stream<OP_FUSED> (lq_fq_fwd_bwd_fused, traversal)", t_k4, BYTES_FUSED)):
         gbs = nbytes / (t_us * 1e-6) / 1e9

@@ -333,17 +333,21 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         if constexpr (OP == OP_FWD) {
             static const int off_rb = tune_int("LQ_TUNE_S2", 0);
             const int64_t nn = p.outer * p.G * p.inner;
-            const bool poor_fill = (double)pl.L / (double)(pl.nc * pl.CH) < 0.95;      // e.g. rows of 1600 = 1024 + 576: 5.65 -> 6.3 TB/s
-            if (!(off_rb & 256) && p.G > 1 && (pl.L % 32 != 0 || poor_fill || (off_rb & 4096)) && aligned(p.P, 16) && aligned(p.out, 16)) {
-                // rows that are not a whole number of 128-byte lines, or that fill their chunks poorly: one group per float4 when
-                // L % 4 == 0 (group mode 0 / 2), else a float4 may straddle a row end (6 / 7)
+            // K1 of long rows as the flat one-shot stream too: one group per float4 when L % 4 == 0 (group mode 0 / 2) -- rows that
+            // are not whole 128-byte lines (4100: 5.4 -> 6.3 TB/s), rows that fill their chunks poorly (1600 = 1024 + 576: 5.65 ->
+            // 6.3) and, by 2 %, the well-filled aligned rows as well (BENCH tensor, K1 alone on four buffer sets, three interleaved
+            // runs: 48.6-48.9 us against 49.8-49.9 for the row stream; profiles/r02/bench_k1_row_stream_vs_flat.txt; development
+            // knob 32768 restores the row stream for them).  L % 4 != 0: a float4 may straddle a row end (6 / 7), see below.
+            const bool poor_fill = (double)pl.L / (double)(pl.nc * pl.CH) < 0.95;
+            if (!(off_rb & 256) && (pl.L % 32 != 0 || poor_fill || !(off_rb & 32768)) && aligned(p.P, 16) && aligned(p.out, 16)) {
                 const int64_t nv = nn >> 2;
                 const int rem = (int)(nn & 3);
                 const int64_t blocks = ceil_div(nv + (rem ? 1 : 0), 512);
                 if (blocks <= 2147483647ll) {
                     const bool ntb = numel * 4.0 >= (double)kNtBytes;
                     const bool wide = nn >= 4294967296ll;
-#define LQ_FLATR(NT_, GM_) hipLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, p, fx, nv, rem)
+                    // hipExtLaunchKernelGGL: with lq_profile_events() set, the events take the kernel's own begin / end timestamps
+#define LQ_FLATR(NT_, GM_) hipExtLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, g_prof_start, g_prof_stop, 0, p, fx, nv, rem)
                     if (pl.L % 4 == 0) {
                         if (ntb) { if (wide) LQ_FLATR(1, 2); else LQ_FLATR(1, 0); }
                         else { if (wide) LQ_FLATR(0, 2); else LQ_FLATR(0, 0); }

@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = sorted(glob.glob(f"{out}/{c}/*/*counter_collection.csv"), key=os.path.getsize)[-1]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "lq::k_row_stream" in r["Kernel_Name"] and r["Counter_Name"] == c:
+        if ("lq::k_row_stream" in r["Kernel_Name"] or "lq::k_flat_fwd" in r["Kernel_Name"]) and r["Counter_Name"] == c:
             agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         res[k][c] = sum(v) / len(v)
