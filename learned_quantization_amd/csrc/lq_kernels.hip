@@ -606,7 +606,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         return check_hip("pipelined column launch") ? -1 : 1;
     }
     if constexpr (OP == OP_FWD) {
-        return 0;                                      // row-small forward whose float4s straddle groups: cannot happen (L % 4 == 0 there)
+        return 0;                                      // a forward none of the flat forms above took (e.g. 2^32 or more elements in column mode)
     } else {
         // MODE_ROW_SMALL, scale-gradient ops.  Rows off the 16-byte grid (or, development knob 1024, any row of 68..1020
         // elements): aligned float4 windows (lq_stream2.hpp k_row_win)

@@ -10,13 +10,16 @@
 //     reduction through ds_bpermute, f64 mean, direct emit from 8 of 64 lanes) is paid once per 128 bytes of each stream.
 // Hence:
 //   k_flat_fwd        K1 (no reduction) of ANY descriptor as a flat stream, one float4 per thread and no loop -- the shape
-//                     of the row-stream kernel; the group of an element comes from its flat index (32-bit arithmetic).
+//                     of the row-stream kernel; the group of an element comes from its flat index (invariant-divisor
+//                     arithmetic, lq_fastdiv.hpp).  Since the end of round 2 also the forward of long aligned rows (BENCH).
 //   k_col_pipe        column tile with a software pipeline: the loads of iteration i+1 are issued BEFORE the stores of
 //                     iteration i, so the vmcnt wait that covers them does not include those stores.
-//   k_col_periodic_pipe   the same pipeline for the periodic float4 form (C <= 64).
+//   k_col_periodic_pipe   the same pipeline for the periodic float4 form (C <= 64; also 64 < C <= 512 where a tile would
+//                     leave lanes idle or start its rows inside a 128-byte line).
 //   k_flat_cols       C = 8, 16, 32, 64 as a flat one-shot stream with an xor-shuffle tree over the lanes that share columns
 //                     (K1 and K4 with two float4 per thread and stream, K2 with four).
-//   k_row_win         rows of 65..1023 elements of any alignment (scale-gradient ops): aligned float4 windows per row.
+//   k_row_win         rows of 65..1023 elements of any alignment, and of 1153..1945 where the row stream's two chunks fill
+//                     poorly (scale-gradient ops): a team (up to one wave) per row reads the aligned float4 window of the row.
 //   k_row_seg         rows of 5..64 elements off the 16-byte grid: one flat window per block, segmented reduction through LDS.
 //   k_row_tiny        rows of <= 64 elements: U passes of rows per wave with all loads up front, DPP team reductions
 //                     (VALU only), ONE emit per wave in which lane (team, u) finishes row (u, team).
