@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define LQ_ABI_VERSION 2
+#define LQ_ABI_VERSION 3
 
 typedef enum lq_status {
     LQ_OK = 0,
@@ -251,7 +251,10 @@ int lq_selftest_uniform_division(uint64_t seed, uint32_t blocks, uint32_t pairs_
  *   lq_fq_forward_oihw     writes out (HWIO, as lq_fq_forward) AND out_oihw[(o*ci + c)*hw + h] = out[(h*ci + c)*co + o];
  *   lq_fq_scale_grad_oihw  takes dy in OIHW order, computes ds exactly as lq_fq_scale_grad would on the un-permuted dy
  *                          (same traversal, same summation order: bit-identical) and writes dP = dy in HWIO order.
- * hw = kh*kw; hw*ci*co must equal outer*G*inner.  Weight-sized tensors (below 2^32 elements).                            */
+ * hw = kh*kw; hw*ci*co must equal outer*G*inner.  Weight-sized tensors (below 2^32 elements).
+ * Kernels of at most 9 taps with co % 4 == 0 and one of the reference's four orientations run as LDS tiles (whole 128-byte
+ * lines on both the HWIO and the OIHW side); lq_fq_scale_grad_oihw then needs lq_conv_workspace_bytes() of scratch.      */
+size_t lq_conv_workspace_bytes(int64_t hw, int64_t ci, int64_t co, int64_t outer, int64_t G, int64_t inner);
 int lq_fq_forward_oihw(const float* P, const float* s, float* out, float* out_oihw, int64_t hw, int64_t ci, int64_t co,
                        int64_t outer, int64_t G, int64_t inner, void* stream);
 int lq_fq_scale_grad_oihw(const float* P, const float* s, const float* dy_oihw, float lambda, float* ds, float* dP,

@@ -66,6 +66,7 @@ SIGNATURES.update({
     "lq_batch_forward": (_c_int, [_c_p, _c_p]),
     "lq_batch_scale_grad": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
     "lq_batch_scale_grad_oihw": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
+    "lq_conv_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "lq_fq_forward_oihw": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "lq_fq_scale_grad_oihw": (_c_int, [_c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p, _c_sz, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "lq_batch_scale_adam": (_c_int, [_c_p, _c_d, _c_d, _c_d, _c_d, _c_i64, _c_p, _c_int, _c_p]),

@@ -2,6 +2,7 @@
 #ifndef LQ_BATCH_HPP_
 #define LQ_BATCH_HPP_
 #include "lq_aux_kernels.hpp"
+#include "lq_conv_tile.hpp"
 
 namespace lq {
 
@@ -9,11 +10,16 @@ namespace lq {
 //  Multi-tensor batch (SURVEY f-4): the 4 / 12 / 40 weight-sized tensors a training step fake-quantises
 //  are latency-bound one by one (each launch costs more than its work).  A batch is a device-resident
 //  table of tasks; ONE launch covers every tensor's traversal (each 256-thread block finds its task by
-//  binary search over the block prefix) and ONE launch finalizes every group of every tensor.  The per-
-//  tensor code is exactly the single-tensor traversal bodies above, so results are bit-identical.
+//  binary search over a contiguous block-prefix array) and ONE launch finalizes every group of every tensor.
+//  The per-tensor code is the single-tensor traversal bodies, or -- conv kernels with an OIHW companion -- the LDS tile
+//  of lq_conv_tile.hpp; forward outputs, max|q| and vote counts are bit-identical to the single-tensor entry points by
+//  construction, the vote sums because they are exact (lq_common.hpp, Acc).
+//  Tasks are ordered by decreasing work per block, so the heavy tiles start first and the light blocks fill the tail.
 // ------------------------------------------------------------------------------------------
+constexpr int MODE_CONV_TILE = 3;
 struct Task {
     Params p;                 // pa/pb/pc are rebound to the batch workspace inside the kernel
+    ConvTile ct;              // mode == MODE_CONV_TILE
     float* ds;                // scale gradient output [G]
     float* dp;                // dP in HWIO order (conv kernels with an OIHW companion), else NULL
     float* mb;                // batch-owned per-group max(|P|/s)      (MaxBin penalty)
@@ -22,7 +28,7 @@ struct Task {
     int64_t R, L, nc;         // row modes (block size 256)
     int64_t C, rps, nbx;      // column mode (rps = rows per block, nbx = blocks along the columns)
     int col_variant, pad1;
-    int64_t np_pad;           // padded partial count; this task's workspace slice is 3 * np_pad words
+    int64_t np_pad;           // padded partial count; this task's workspace slice is 4 * np_pad words (u32, u32, f64)
     int64_t ws_off;           // offset of the slice in uint32 words
     int64_t gstride, n1, stride1, n2;   // finalize geometry
     double count;             // elements per group
@@ -30,12 +36,13 @@ struct Task {
     uint32_t first_group;     // prefix over groups
 };
 
-__device__ __forceinline__ int find_task(const Task* __restrict__ tasks, int ntasks, uint32_t b, bool by_group) {
+// prefix[i] = first block (or first group) of task i, one contiguous array: the 5-7 probes of the search stay inside one or
+// two cache lines (probing the 400-byte task records themselves cost a cache miss per probe at the head of every block)
+__device__ __forceinline__ int find_task(const uint32_t* __restrict__ prefix, int ntasks, uint32_t b) {
     int lo = 0, hi = ntasks - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        const uint32_t first = by_group ? tasks[mid].first_group : tasks[mid].first_block;
-        if (first <= b) lo = mid;
+        if (prefix[mid] <= b) lo = mid;
         else hi = mid - 1;
     }
     return lo;
@@ -55,9 +62,13 @@ struct CoefPack {           // per-tensor upstream coefficient of a penalty term
 //           2 = penalty pass: pk.dy[] are the gradient buffers to ACCUMULATE into, cf.c[] the upstream coefficients;
 //           3 = as 1, but the gradients of conv kernels with an OIHW companion arrive in OIHW order (OP_BWD_PERM)
 template <int OP>
-__global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restrict__ tasks, int ntasks, uint32_t* ws, PtrPack pk,
-                                                           int use_pack, CoefPack cf) {
-    const int ti = find_task(tasks, ntasks, blockIdx.x, false);
+__global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restrict__ tasks, const uint32_t* __restrict__ prefix, int ntasks,
+                                                           uint32_t* ws, PtrPack pk, int use_pack, CoefPack cf) {
+    // one LDS scratch: the column traversal's accumulators, or the transposed tile of a conv kernel
+    constexpr int kColBytes = OpT<OP>::kReduce ? kBlock * 4 * (int)sizeof(Acc) : 16;
+    constexpr int kTileBytes = (OP == OP_FWD_PERM || OP == OP_BWD_PERM) ? kCtLdsWords * 4 : 16;
+    __shared__ __align__(16) unsigned char smem[kColBytes > kTileBytes ? kColBytes : kTileBytes];
+    const int ti = find_task(prefix, ntasks, blockIdx.x);
     const Task& t = tasks[ti];
     Params p = t.p;
     if (use_pack == 1) p.dy = pk.dy[ti];
@@ -80,9 +91,16 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
     }
     p.pa = ws + t.ws_off;
     p.pb = p.pa + t.np_pad;
-    p.pc = reinterpret_cast<float*>(p.pb + t.np_pad);
+    p.pc = reinterpret_cast<double*>(p.pb + t.np_pad);
     const uint32_t b = blockIdx.x - t.first_block;
-    if (t.mode == 0) {
+    if (t.mode == MODE_CONV_TILE) {
+        if constexpr (OP == OP_FWD_PERM) {
+            conv_tile_fwd(p, t.ct, b, reinterpret_cast<float*>(smem));
+        } else if constexpr (OP == OP_BWD_PERM) {
+            if (p.dy_perm) conv_tile_bwd<true>(p, t.ct, b, reinterpret_cast<float*>(smem));
+            else conv_tile_bwd<false>(p, t.ct, b, reinterpret_cast<float*>(smem));
+        }
+    } else if (t.mode == 0) {
         const uint32_t nc = (uint32_t)t.nc;
         const uint32_t row = b / nc, ck = b - row * nc;
         const int64_t g = (int64_t)(row % (uint32_t)p.G);
@@ -92,19 +110,19 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
         if (t.vec) row_small_body<OP, 4>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
         else row_small_body<OP, 1>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
     } else {
-        __shared__ Acc col_lds[OpT<OP>::kReduce ? kBlock * 4 : 1];
-        col_body<OP, false>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b, t.n1, col_lds);
+        col_body<OP, false>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b, t.n1, reinterpret_cast<Acc*>(smem));
     }
 }
 
 template <int OP, int BS = 64>     // BS = 256 when some group of the batch has more than 256 partials (host decides)
-__global__ __launch_bounds__(BS) void k_batch_finalize(const Task* __restrict__ tasks, int ntasks, uint32_t* ws, int accum = 0) {
-    const int ti = find_task(tasks, ntasks, blockIdx.x, true);
+__global__ __launch_bounds__(BS) void k_batch_finalize(const Task* __restrict__ tasks, const uint32_t* __restrict__ gprefix, int ntasks,
+                                                       uint32_t* ws, int accum = 0) {
+    const int ti = find_task(gprefix, ntasks, blockIdx.x);
     const Task& t = tasks[ti];
     Params p = t.p;
     p.pa = ws + t.ws_off;
     p.pb = p.pa + t.np_pad;
-    p.pc = reinterpret_cast<float*>(p.pb + t.np_pad);
+    p.pc = reinterpret_cast<double*>(p.pb + t.np_pad);
     FinGeom f;
     f.groups = p.G;
     f.gstride = t.gstride;
@@ -122,11 +140,11 @@ __global__ __launch_bounds__(BS) void k_batch_finalize(const Task* __restrict__ 
 // Scale gradients of the MaxBin (kind 0) and Inverse (kind 2) penalty terms for every group of every tensor:
 //   maxbin   ds[g] = -((c/G) * mb[g]) / s[g]          (custom_loss_functions.py:92,110; reduce_max + RealDiv gradients)
 //   inverse  ds[g] = s[g] == 0 ? 0 : -((c/G) / s[g]) / s[g]                     (:252-255)
-__global__ __launch_bounds__(kBlock) void k_batch_penalty_ds(const Task* __restrict__ tasks, int ntasks, uint32_t total_groups, int kind,
-                                                             CoefPack cf, int accum) {
+__global__ __launch_bounds__(kBlock) void k_batch_penalty_ds(const Task* __restrict__ tasks, const uint32_t* __restrict__ gprefix, int ntasks,
+                                                             uint32_t total_groups, int kind, CoefPack cf, int accum) {
     const uint32_t gg = blockIdx.x * kBlock + threadIdx.x;
     if (gg >= total_groups) return;
-    const int ti = find_task(tasks, ntasks, gg, true);
+    const int ti = find_task(gprefix, ntasks, gg);
     const Task& t = tasks[ti];
     const uint32_t g = gg - t.first_group;
     const float up = cf.c[ti], sg = t.p.s[g], G = (float)t.p.G;

@@ -36,7 +36,7 @@ struct Params {
     int accum;           // penalty backward: add to the existing contents of `out` instead of overwriting
     uint32_t* pa;        // partials, SoA
     uint32_t* pb;
-    float* pc;
+    double* pc;          // vote sums are carried in f64 (exact for lambda < 4e-4, see Acc below)
     int64_t outer, G, inner;
     // direct emit (scale-gradient ops whose groups have exactly one partial: biases, row-wise Dense, one row per group):
     // the traversal writes the op's outputs itself and the finalize launch is skipped
@@ -75,15 +75,25 @@ struct Ctx {
     int sure_ok;  // lam_hi*b cannot underflow for any b this row can produce (b >= min(s, eps_f32))
 };
 
-// Narrow accumulator (inside streaming kernels) and wide accumulator (finalize).
+// Narrow accumulator (inside the traversal kernels) and wide accumulator (finalize).
+//
+// The sum `c` is carried in f64 from the first addition on.  For the nested-quantization vote (custom_layers.py:84 / :110) with
+// lambda < 4e-4 -- every published threshold; there |tanh(d)| == d in fp32 -- this makes the sum EXACT and therefore independent
+// of the order in which a traversal visits the elements: with lambda in [2^e, 2^(e+1)) every term d = RN(lambda - ratio),
+// 0 <= ratio < lambda, is a multiple of 2^(e-24) (Sterbenz for ratio >= lambda/2; one rounding at ulp(lambda/2) below) and
+// at most lambda, i.e. an integer below 2^25 in units of 2^(e-24); a group of up to 2^28 elements sums to less than 2^53 units.
+// Every traversal (row stream, tiles, columns, multi-tensor batch, conv tiles, any block size, any number of ranks' partials
+// merged in any order) therefore yields the SAME bits of ds -- and that value is the correctly rounded mean.  For lambda >= 4e-4
+// the terms are polynomial / ocml tanh values without a common quantum: there the f64 sum still depends on the order, below
+// 2^-50 relative, which survives the final rounding to fp32 only when the mean sits on a rounding boundary.
 template <typename TB, typename TC>
 struct AccT {
     uint32_t a;
     TB b;
     TC c;
 };
-using Acc = AccT<uint32_t, float>;
-using AccW = AccT<double, double>;   // finalize: count and sum in f64 (counts are exact below 2^53)
+using Acc = AccT<uint32_t, double>;
+using AccW = AccT<double, double>;   // finalize: count in f64 as well (counts are exact below 2^53)
 
 enum OpKind {
     OP_FWD = 0,        // K1

@@ -40,6 +40,7 @@
 #include <string.h>
 
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "lq_hip.h"
@@ -77,13 +78,27 @@ struct Plan {
 
 static int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Development knobs.  The shipped library reads NO environment variable: the traversal plan, the partial layout and with
+// them the workspace size are pure functions of the descriptor and the pointers' alignment.  `make dev` (-DLQ_DEV_KNOBS,
+// tools/ only) turns LQ_KNOB into a getenv lookup and compiles the alternative launches the tuning sweeps of profiles/r02
+// were made with; every use is marked.
+#ifdef LQ_DEV_KNOBS
+static int knob_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#define LQ_KNOB(var, name, dflt) static const int var = knob_env(name, dflt)
+#else
+#define LQ_KNOB(var, name, dflt) constexpr int var = (dflt)
+#endif
+
 static bool flat_cols_ok(int64_t C) { return C == 8 || C == 16 || C == 32 || C == 64; }
-static int64_t colx_max_inner() {        // development knob LQ_TUNE_COLX_INNER: rows shorter than this may run in column mode (see make_plan)
-    static const int64_t v = getenv("LQ_TUNE_COLX_INNER") ? atoll(getenv("LQ_TUNE_COLX_INNER")) : 200;
+static int64_t colx_max_inner() {        // rows shorter than this may run in column mode (see make_plan)
+    LQ_KNOB(v, "LQ_TUNE_COLX_INNER", 200);
     return v;
 }
-static int64_t periodic_target() {      // development knob LQ_TUNE_PER_NB: block count of the periodic column form (default 2048)
-    static const int64_t v = getenv("LQ_TUNE_PER_NB") ? atoll(getenv("LQ_TUNE_PER_NB")) : 2048;
+static int64_t periodic_target() {      // block count of the periodic column form
+    LQ_KNOB(v, "LQ_TUNE_PER_NB", 2048);
     return v > 0 ? v : 2048;
 }
 static int64_t periodic_blocks(int64_t C) { return C * ((periodic_target() + C / 2) / C); }      // ~2048 blocks, a multiple of C
@@ -115,7 +130,7 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
         // (256, 2048, 7 x 7)) are instruction-bound as rows -- per-row context, team reduction and emit every 100-400 bytes --
         // but as the matrix [outer][G * inner] a lane keeps its four columns, contexts and accumulators across all layers:
         // column mode for them too, at streaming size and when the matrix rows are whole 128-byte lines.
-        static const int colx = getenv("LQ_TUNE_COLX") ? atoi(getenv("LQ_TUNE_COLX")) : 1;      // development knob: 0 = rows
+        LQ_KNOB(colx, "LQ_TUNE_COLX", 1);      // 0 = rows
         const bool short_rows_many_layers = colx && inner >= 16 && inner < colx_max_inner() && outer >= 32 && (G * inner) % 32 == 0 &&
                                             G * inner > 64 && (double)N >= (double)kPeriodic4Min && !(inner % 4 == 0 && (inner & (inner - 1)) == 0);
         if ((inner < 16 && outer > 1) || short_rows_many_layers) {
@@ -194,10 +209,12 @@ static Plan make_plan(int64_t outer, int64_t G, int64_t inner, int force_bs = 0)
             // multi-tensor batch kernels use -- so batched and single-tensor results are bit-identical there.
             pl.bs = (L >= 2048 && (double)R * (double)L >= 4194304.0) ? 512 : 256;
             if (force_bs) pl.bs = force_bs;
-            else if (const char* e = getenv("LQ_TUNE_BS")) {   // development knob (tools/): force the streaming block size
-                const int v = atoi(e);
+#ifdef LQ_DEV_KNOBS
+            else {                                             // force the streaming block size
+                LQ_KNOB(v, "LQ_TUNE_BS", 0);
                 if ((v == 256 || v == 512 || v == 1024) && L >= v * 4) pl.bs = v;
             }
+#endif
             pl.CH = pl.bs * 4;
             pl.nc = row_chunks(L, pl.CH);
             if (pl.bs == 512) pl.np_ws = R * row_chunks(L, 1024);      // launch_traverse may cut such rows into 1024-element chunks
@@ -258,7 +275,7 @@ static int check_desc(int64_t outer, int64_t G, int64_t inner) {
 static size_t ws_bytes_for(const Plan& pl) {
     size_t np = (size_t)(pl.np_ws > pl.np ? pl.np_ws : pl.np);
     np = (np + 63) / 64 * 64;
-    return np * 12 + 256;
+    return np * 16 + 256;
 }
 
 static int bind_ws(Params& p, const Plan& pl, void* ws, size_t ws_bytes) {
@@ -268,7 +285,7 @@ static int bind_ws(Params& p, const Plan& pl, void* ws, size_t ws_bytes) {
     size_t np = ((size_t)(pl.np_ws > pl.np ? pl.np_ws : pl.np) + 63) / 64 * 64;
     p.pa = reinterpret_cast<uint32_t*>(ws);
     p.pb = p.pa + np;
-    p.pc = reinterpret_cast<float*>(p.pb + np);
+    p.pc = reinterpret_cast<double*>(p.pb + np);
     return LQ_OK;
 }
 
@@ -300,12 +317,8 @@ static void col_variant(const Plan& pl, const void* P, const void* dy, const voi
     }
 }
 
-// development knob: LQ_TUNE_S2 = bit mask of round-2 streaming forms to DISABLE (1 flat K1, 2 pipelined column tile,
-// 4 pipelined periodic columns, 8 tiny-row passes); LQ_TUNE_PIPE = "U,NW" of the column tile; LQ_TUNE_TINY_U = passes
-static int tune_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
+// development knobs of the streaming forms: LQ_TUNE_S2 = bit mask of forms to DISABLE (1 flat K1, 2 pipelined column tile,
+// 4 pipelined periodic columns, 8 tiny-row passes, ...); LQ_TUNE_PIPE = U*10 + NW of the column tile; LQ_TUNE_TINY_U = passes
 
 // Streaming-size (>= 4 M elements) forms of lq_stream2.hpp.  Returns 1 when it launched the traversal, 0 when the
 // round-1 traversal should run, < 0 on error.
@@ -331,7 +344,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     if (pl.mode == MODE_ROW_BIG) {
         // long rows off the 16-byte grid: K1 as a line-aligned flat stream (lq_stream2.hpp k_flat_fwd, group mode 6 / 7)
         if constexpr (OP == OP_FWD) {
-            static const int off_rb = tune_int("LQ_TUNE_S2", 0);
+            LQ_KNOB(off_rb, "LQ_TUNE_S2", 0);
             const int64_t nn = p.outer * p.G * p.inner;
             // K1 of long rows as the flat one-shot stream too: one group per float4 when L % 4 == 0 (group mode 0 / 2) -- rows that
             // are not whole 128-byte lines (4100: 5.4 -> 6.3 TB/s), rows that fill their chunks poorly (1600 = 1024 + 576: 5.65 ->
@@ -368,12 +381,12 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
             // Rows of 1153..1533 elements are two 1024-chunks, the second one 13-50 % full (35 x 35 planes: 1225 = 1024 + 201) --
             // too few bytes in flight per resident thread: K2 / K4 4.0 / 3.9 TB/s.  One wave per row through the row-window
             // kernel instead (5 or 6 float4 per lane: 80-100 % of the lanes carry data); partials as in the row-small mode.
-            static const int off_rb = tune_int("LQ_TUNE_S2", 0);
+            LQ_KNOB(off_rb, "LQ_TUNE_S2", 0);
             const int nwin = (int)(pl.L % 4 ? (pl.L + 6) / 4 : pl.L / 4);
             const bool al = aligned(p.P, 16) && aligned(p.dy, 16) && (!O::kStore || aligned(p.out, 16));
             // (rows of 1534..2047 elements: two chunks that fill >= 75 % -- the row stream is as good or better (1800: K2 / K4 6.4 / 5.8
             // against 6.0 / 5.5 with 8 float4 per lane) unless the rows are off the 16-byte grid (1535, 1537: 5.0 / 4.7 -> 6.1 / 5.6))
-            static const int win_max = tune_int("LQ_TUNE_WIN_MAX", 384);      // development knob: widest window (float4) for rows ON the grid
+            LQ_KNOB(win_max, "LQ_TUNE_WIN_MAX", 384);      // development knob: widest window (float4) for rows ON the grid
             const bool wide_ok = pl.L % 4 != 0 && (double)pl.L / 2048.0 < 0.95;
             if (!(off_rb & 128) && pl.bs == 256 && pl.nc == 2 && (nwin <= win_max || wide_ok) && nwin <= 512 && al && !p.direct && pl.R < 4294967296ll) {
                 const int64_t blocks = ceil_div(pl.R, (int64_t)kWavesPerBlock);
@@ -402,7 +415,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     }
     const bool al16 = aligned(p.P, 16) && (!O::kDy || aligned(p.dy, 16)) && (!O::kStore || aligned(p.out, 16));
     if (!al16) return 0;
-    static const int off = tune_int("LQ_TUNE_S2", 0);
+    LQ_KNOB(off, "LQ_TUNE_S2", 0);
     const bool nt = numel * 4.0 >= (double)kNtBytes;
     const int64_t n = p.outer * p.G * p.inner;
     // ---- K1 as a flat stream: whenever a float4 has one group (inner % 4 == 0) -- tiny rows, rows of 8..1020 elements,
@@ -441,7 +454,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
             }
         }
         // every other column-mode forward (several groups inside a float4: C = 3, 5, 10, 30; inner = 2, 3, 5, 15): gathered scales
-        static const int gather_on = tune_int("LQ_TUNE_GATHER", 1);
+        LQ_KNOB(gather_on, "LQ_TUNE_GATHER", 1);
         if (gather_on && !(off & 1) && pl.mode == MODE_COL && !one_group && !scale4 && !scale4u && !cols_pow2 && n < 4294967296ll) {
             const int64_t nv = n >> 2;
             const int rem = (int)(n & 3);
@@ -484,7 +497,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         // tree and the barrier at the end of so short a wave (4.3-5.4 TB/s); with four the epilogue is paid once per 8 KB of each
         // stream: 6.0-6.2 TB/s against 5.5-5.6 for the periodic form.  (K4 with four: 5.6-5.9 against 5.7-6.1 with two.)
         if constexpr (OP == OP_BWD) {
-            static const int fc_k2 = tune_int("LQ_TUNE_FC_K2", 4);      // development knob: 0 = the periodic form
+            LQ_KNOB(fc_k2, "LQ_TUNE_FC_K2", 4);      // development knob: 0 = the periodic form
             if (fc_k2 == 4 && pl.C <= 64 && pl.per4 && flat_cols_ok(pl.C) && nt && !(off & 64)) {
                 const int64_t nv = n >> 2;
                 const int64_t fb = ceil_div(nv, (int64_t)kFlatColsBlock * 4);
@@ -515,7 +528,8 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         }
         if (pl.C <= 64) {
             if ((off & 4) || !pl.per4) return 0;
-            static const int per = tune_int("LQ_TUNE_PERIODIC", 0);      // development knob: U*10 + (block size / 256)
+#ifdef LQ_DEV_KNOBS
+            LQ_KNOB(per, "LQ_TUNE_PERIODIC", 0);      // U*10 + (block size / 256)
             if (nt && (per == 12 || per == 22)) {
                 // 512-thread blocks, half as many: the finalize that follows must walk the partial layout this launch produces
                 const int64_t nb2 = ((pl.ysplit / 2) / pl.C) * pl.C;
@@ -528,17 +542,21 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                     return check_hip("periodic column launch") ? -1 : 1;
                 }
             }
-            if (nt && per == 11) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1, 256>), dim3((unsigned)pl.ysplit), dim3(256), 0, st, p, (int)pl.C, pl.ysplit);
-            else if (nt && per == 21) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 2, 256>), dim3((unsigned)pl.ysplit), dim3(256), 0, st, p, (int)pl.C, pl.ysplit);
-            else if (nt && per == 41) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 4, 256>), dim3((unsigned)pl.ysplit), dim3(256), 0, st, p, (int)pl.C, pl.ysplit);
+            if (nt && (per == 11 || per == 21 || per == 41)) {
+                if (per == 11) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1, 256>), dim3((unsigned)pl.ysplit), dim3(256), 0, st, p, (int)pl.C, pl.ysplit);
+                else if (per == 21) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 2, 256>), dim3((unsigned)pl.ysplit), dim3(256), 0, st, p, (int)pl.C, pl.ysplit);
+                else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 4, 256>), dim3((unsigned)pl.ysplit), dim3(256), 0, st, p, (int)pl.C, pl.ysplit);
+                return check_hip("periodic column launch") ? -1 : 1;
+            }
+#endif
             // K4 with C >= 16: one float4 per stream in flight (98 VGPRs, 5 waves per SIMD) measured 5.67-5.75 TB/s at C = 64 against
             // 5.30-5.49 with two (128 VGPRs); at C = 3 the other way round (5.57 against 5.24)
-            else if (nt && OP == OP_FUSED && pl.C >= 16) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
+            if (nt && OP == OP_FUSED && pl.C >= 16) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             else if (nt) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             return check_hip("periodic column launch") ? -1 : 1;
         }
-        static const int per_cmax = tune_int("LQ_TUNE_PER_CMAX", 256);      // development knob: 0 = always the tile
+        LQ_KNOB(per_cmax, "LQ_TUNE_PER_CMAX", 256);      // development knob: 0 = always the tile
         if (pl.C <= per_cmax && pl.C <= 256 && (pl.C < 192 || pl.C % 32 != 0) && periodic_blocks(pl.C) * pl.C <= pl.np) {
             // 64 < C <= 256: a tile narrower than 256 columns leaves lanes idle and, when C % 32 != 0, starts every row in the
             // middle of a 128-byte line; the periodic form is a flat line-aligned stream for any C.  Measured (K2 / K4 TB/s,
@@ -572,7 +590,8 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         const int64_t nbx = ceil_div(pl.C, 256);
         {
             // rows per block by operation; never fewer than the plan's (the workspace was sized for the plan's partial count)
-            static const int64_t rb_bwd = tune_int("LQ_TUNE_COL_RB_K2", (int)kColRbBwd), rb_st = tune_int("LQ_TUNE_COL_RB_K4", (int)kColRbFused);
+            LQ_KNOB(rb_bwd, "LQ_TUNE_COL_RB_K2", (int)kColRbBwd);
+            LQ_KNOB(rb_st, "LQ_TUNE_COL_RB_K4", (int)kColRbFused);
             int64_t rb = (OP == OP_BWD) ? rb_bwd : rb_st;
             if (rb < pl.rps) rb = pl.rps;
             if (rb > p.outer) rb = p.outer;
@@ -584,21 +603,23 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         }
         const int64_t blocks = nbx * pl.ysplit;
         if (blocks > 2147483647ll) return 0;
-        static const int pipe_r = tune_int("LQ_TUNE_PIPE", 28);      // U*10 + NW (scale-gradient ops)
-        static const int pipe_f = tune_int("LQ_TUNE_PIPE_FWD", 28);
+        LQ_KNOB(pipe_r, "LQ_TUNE_PIPE", 28);      // U*10 + NW (scale-gradient ops)
+        LQ_KNOB(pipe_f, "LQ_TUNE_PIPE_FWD", 28);
         const int pipe = (OP == OP_FWD) ? pipe_f : pipe_r;
 #define LQ_PIPE(NT_, U_, NW_) hipLaunchKernelGGL((k_col_pipe<OP, NT_, U_, NW_>), dim3((unsigned)blocks), dim3(NW_ * 64), 0, st, p, pl.C, pl.rps, nbx)
-        static const int xcd_remap = tune_int("LQ_TUNE_XCD", 1);      // development knob: 0 = natural block order for C % 32 != 0
+        LQ_KNOB(xcd_remap, "LQ_TUNE_XCD", 1);      // development knob: 0 = natural block order for C % 32 != 0
         if (ua) {
             if (nt) hipLaunchKernelGGL((k_col_pipe<OP, 1, 2, 8, 1>), dim3((unsigned)blocks), dim3(512), 0, st, p, pl.C, pl.rps, nbx);
             else hipLaunchKernelGGL((k_col_pipe<OP, 0, 2, 8, 1>), dim3((unsigned)blocks), dim3(512), 0, st, p, pl.C, pl.rps, nbx);
         } else if (OP == OP_BWD && nt && pl.C % 32 != 0 && nbx > 1 && xcd_remap && pipe == 28) {
             // rows that are not whole lines: neighbouring column blocks share a line -- keep them on one XCD (lq_stream2.hpp)
-            hipLaunchKernelGGL((k_col_pipe<OP, 1, 2, 8, 2>), dim3((unsigned)blocks), dim3(512), 0, st, p, pl.C, pl.rps, nbx);
+            if constexpr (OP == OP_BWD) hipLaunchKernelGGL((k_col_pipe<OP, 1, 2, 8, 2>), dim3((unsigned)blocks), dim3(512), 0, st, p, pl.C, pl.rps, nbx);
         } else if (nt) {
-            if (pipe == 14) LQ_PIPE(1, 1, 4); else if (pipe == 44) LQ_PIPE(1, 4, 4); else if (pipe == 28) LQ_PIPE(1, 2, 8);
-            else if (pipe == 18) LQ_PIPE(1, 1, 8); else if (pipe == 48) LQ_PIPE(1, 4, 8); else if (pipe == 24) LQ_PIPE(1, 2, 4);
-            else LQ_PIPE(1, 2, 8);
+#ifdef LQ_DEV_KNOBS
+            if (pipe == 14) LQ_PIPE(1, 1, 4); else if (pipe == 44) LQ_PIPE(1, 4, 4); else if (pipe == 18) LQ_PIPE(1, 1, 8);
+            else if (pipe == 48) LQ_PIPE(1, 4, 8); else if (pipe == 24) LQ_PIPE(1, 2, 4); else
+#endif
+            LQ_PIPE(1, 2, 8);
         } else {
             LQ_PIPE(0, 2, 8);
         }
@@ -633,7 +654,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                 return check_hip("row-segment launch") ? -1 : 1;
             }
         }
-        static const int win_all = tune_int("LQ_TUNE_WIN", 1);      // 0: rows with L % 4 == 0 and L > 64 keep the round-1 row-small kernel
+        LQ_KNOB(win_all, "LQ_TUNE_WIN", 1);      // 0: rows with L % 4 == 0 and L > 64 keep the round-1 row-small kernel
         if (!(off & 128) && pl.L >= 5 && pl.R < 4294967296ll && (pl.L % 4 != 0 || (win_all && pl.L > 64))) {
             const int nwin = (int)(pl.L % 4 ? (pl.L + 3 + 3) / 4 : pl.L / 4);     // float4s of the widest window of a row
             int lg = 1;
@@ -666,7 +687,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         }
         if ((off & 8) || pl.L > 64 || pl.L < 8 || pl.L % 4 != 0) return 0;
         const int lg = row_small_lpr_log2_vec(pl.L);         // 1..4
-        static const int tiny_u = tune_int("LQ_TUNE_TINY_U", 2);
+        LQ_KNOB(tiny_u, "LQ_TUNE_TINY_U", 2);
         int U = (1 << lg) < tiny_u ? (1 << lg) : tiny_u;
         if (U != 2 && U != 4) U = 2;
         const int64_t rows_per_block = (int64_t)kWavesPerBlock * (64 >> lg) * U;
@@ -677,11 +698,19 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
             if (gm == 0) hipLaunchKernelGGL((k_row_tiny<OP, NT_, U_, LG_, 0>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L); \
             else if (gm == 1) hipLaunchKernelGGL((k_row_tiny<OP, NT_, U_, LG_, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L); \
             else hipLaunchKernelGGL((k_row_tiny<OP, NT_, U_, LG_, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L); } while (0)
+#ifdef LQ_DEV_KNOBS
 #define LQ_TINY2(NT_) do { \
             if (lg == 1) LQ_TINY3(NT_, 2, 1); \
             else if (lg == 2) { if (U == 2) LQ_TINY3(NT_, 2, 2); else LQ_TINY3(NT_, 4, 2); } \
             else if (lg == 3) { if (U == 2) LQ_TINY3(NT_, 2, 3); else LQ_TINY3(NT_, 4, 3); } \
             else { if (U == 2) LQ_TINY3(NT_, 2, 4); else LQ_TINY3(NT_, 4, 4); } } while (0)
+#else       // two passes of rows per wave (four measured no better: profiles/r02/tuning_sweeps.txt)
+#define LQ_TINY2(NT_) do { \
+            if (lg == 1) LQ_TINY3(NT_, 2, 1); \
+            else if (lg == 2) LQ_TINY3(NT_, 2, 2); \
+            else if (lg == 3) LQ_TINY3(NT_, 2, 3); \
+            else LQ_TINY3(NT_, 2, 4); } while (0)
+#endif
         if (nt) LQ_TINY2(1); else LQ_TINY2(0);
 #undef LQ_TINY2
 #undef LQ_TINY3
@@ -705,8 +734,9 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         // three 1024-chunks.  Measured, K4 at 512 -> 256 threads: rows of 2500: 4.4 -> 6.0 TB/s, 3000: 5.1 -> 6.1, 5000: 5.8 ->
         // 6.3, 6000 (same fill): 6.2 = 6.2; K2 (two float4 per thread, CH = 4096): 5000: 5.7 -> 6.5, 6000: 5.9 -> 6.6, but a
         // row that is ONE chunk keeps it (2500: 6.8 against 6.3).  The BENCH rows (50176 = 24.5 x 2048) keep 512 threads.
-        static const int tune_chunk = tune_int("LQ_TUNE_CHUNK", 1);     // development knob: 0 = always the plan's block size
-        if (pl.bs == 512 && vec && tune_chunk && !p.direct && !getenv("LQ_TUNE_BS") && pl.np_ws >= pl.R * row_chunks(pl.L, 1024)) {
+        LQ_KNOB(tune_chunk, "LQ_TUNE_CHUNK", 1);     // development knob: 0 = always the plan's block size
+        LQ_KNOB(forced_bs, "LQ_TUNE_BS", 0);
+        if (pl.bs == 512 && vec && tune_chunk && !p.direct && !forced_bs && pl.np_ws >= pl.R * row_chunks(pl.L, 1024)) {
             auto fill = [&](int64_t CH) { return (double)pl.L / (double)(row_chunks(pl.L, CH) * CH); };
             const bool k2_form = (OP == OP_BWD || (OP == OP_FUSED && p.tmode >= 1)) && (double)pl.R * (double)pl.L * 4.0 >= (double)kNtBytes;
             const bool small = k2_form ? (row_chunks(pl.L, 4096) > 1 && fill(1024) > fill(4096) + 0.1) : (fill(1024) > fill(2048) + 0.05);
@@ -732,7 +762,7 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         // there, but 77.7 vs 75.4 us at small lambda).  The unit doubles, so the chunk count halves; the workspace
         // bound (computed for one float4 per thread) still holds.  Four float4 per thread in K2 were measured in round 2:
         // 49.5 against 48.0 us on the BENCH tensor -- not better.
-        static const int tune_u2 = getenv("LQ_TUNE_U2") ? atoi(getenv("LQ_TUNE_U2")) : -1;   // development knob: force 0/1
+        LQ_KNOB(tune_u2, "LQ_TUNE_U2", -1);   // force 0/1
         const bool want_u2 = tune_u2 >= 0 ? tune_u2 == 1 : (OP == OP_BWD || p.tmode >= 1);
         const bool u2 = (OP == OP_BWD || OP == OP_FUSED) && want_u2 && vec && nt && pl.bs == 512;
         // rows with a folded tail or with chunks off the 16-byte grid take the TAIL instantiation (see row_stream_body)
@@ -763,10 +793,13 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         if (VEC_ == 1 || tail1) hipExtLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_, 1, 1>), grid, dim3(BS_), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, pl.nc, grid3d); \
         else hipExtLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_, 1, 0>), grid, dim3(BS_), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, pl.nc, grid3d); } while (0)
         if (vec) {
+#ifdef LQ_DEV_KNOBS
             if (pl.bs == 1024) {
                 if (nt) LQ_LAUNCH_STREAM(4, 1024, 1);
                 else LQ_LAUNCH_STREAM(4, 1024, 0);
-            } else if (pl.bs == 512) {
+            } else
+#endif
+            if (pl.bs == 512) {
                 if (nt) LQ_LAUNCH_STREAM(4, 512, 1);
                 else LQ_LAUNCH_STREAM(4, 512, 0);
             } else {
@@ -774,8 +807,11 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
                 else LQ_LAUNCH_STREAM(4, 256, 0);
             }
         } else {
+#ifdef LQ_DEV_KNOBS
             if (pl.bs == 1024) LQ_LAUNCH_STREAM(1, 1024, 0);
-            else if (pl.bs == 512) LQ_LAUNCH_STREAM(1, 512, 0);
+            else
+#endif
+            if (pl.bs == 512) LQ_LAUNCH_STREAM(1, 512, 0);
             else LQ_LAUNCH_STREAM(1, 256, 0);
         }
 #undef LQ_LAUNCH_STREAM
@@ -849,6 +885,10 @@ static Params base_params(const float* P, const float* s, int64_t outer, int64_t
     p.inner = inner;
     return p;
 }
+
+static bool make_conv_tile(ConvTile& ct, int64_t hw, int64_t ci, int64_t co, int64_t outer, int64_t G, int64_t inner);
+static int64_t conv_tile_partials(const ConvTile& ct, int64_t G);
+static void conv_tile_fin(const ConvTile& ct, int64_t G, int64_t& gstride, int64_t& n1, int64_t& stride1, int64_t& n2);
 
 }  // namespace lq
 
@@ -933,7 +973,26 @@ int lq_fq_forward_oihw(const float* P, const float* s, float* out, float* out_oi
     p.perm_hw = (uint32_t)hw;
     p.perm_ci = (uint32_t)ci;
     p.perm_co = (uint32_t)co;
-    return launch_traverse<OP_FWD_PERM>(pl, p, (hipStream_t)stream);
+    ConvTile ct;
+    if (aligned(P, 16) && aligned(out, 16) && make_conv_tile(ct, hw, ci, co, outer, G, inner)) {      // LDS tiles (lq_conv_tile.hpp)
+        hipLaunchKernelGGL(k_conv_tile_fwd, dim3(ct.ntc * ct.nto), dim3(kBlock), 0, (hipStream_t)stream, p, ct);
+        return check_hip("conv tile forward launch");
+    }
+    return launch_traverse<OP_FWD_PERM>(pl, p, (hipStream_t)stream);      // element-wise companion (kernels with > 9 taps, co % 4 != 0, ...)
+}
+
+size_t lq_conv_workspace_bytes(int64_t hw, int64_t ci, int64_t co, int64_t outer, int64_t G, int64_t inner) {
+    if (outer <= 0 || G <= 0 || inner <= 0) return 0;
+    size_t need = ws_bytes_for(make_plan(outer, G, inner));
+    ConvTile ct;
+    if (hw > 0 && ci > 0 && co > 0 && make_conv_tile(ct, hw, ci, co, outer, G, inner)) {
+        Plan tp;
+        memset(&tp, 0, sizeof(tp));
+        tp.np = conv_tile_partials(ct, G);
+        const size_t t = ws_bytes_for(tp);
+        if (t > need) need = t;
+    }
+    return need;
 }
 
 int lq_fq_scale_grad_oihw(const float* P, const float* s, const float* dy_oihw, float lambda, float* ds, float* dP,
@@ -957,6 +1016,22 @@ int lq_fq_scale_grad_oihw(const float* P, const float* s, const float* dy_oihw, 
     p.perm_co = (uint32_t)co;
     p.lam = lambda;
     p.tmode = (lambda < 4.0e-4f) ? 0 : ((lambda <= 0.25f) ? 1 : 2);
+    ConvTile ct;
+    if (aligned(P, 16) && aligned(dP, 16) && make_conv_tile(ct, hw, ci, co, outer, G, inner)) {       // LDS tiles (lq_conv_tile.hpp)
+        Plan tp;
+        memset(&tp, 0, sizeof(tp));
+        tp.np = conv_tile_partials(ct, G);
+        conv_tile_fin(ct, G, tp.gstride, tp.n1, tp.stride1, tp.n2);
+        if (ws && ws_bytes < ws_bytes_for(tp))
+            return fail(LQ_EWORKSPACE, "lq_fq_scale_grad_oihw: workspace too small: %zu < %zu bytes (size it with lq_conv_workspace_bytes)",
+                        ws_bytes, ws_bytes_for(tp));
+        if ((rc = bind_ws(p, tp, ws, ws_bytes))) return rc;
+        hipLaunchKernelGGL(k_conv_tile_bwd<true>, dim3(ct.ntc * ct.nto), dim3(kBlock), 0, (hipStream_t)stream, p, ct);
+        if ((rc = check_hip("conv tile backward launch"))) return rc;
+        FinGeom f = group_geom(tp, outer, G, inner);
+        f.o0 = ds;
+        return launch_finalize<OP_BWD>(p, f, (hipStream_t)stream);
+    }
     if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
     const bool direct = pl.n1 * pl.n2 == 1;
     if (direct) {
@@ -1203,25 +1278,95 @@ int lq_q_absmax_over_axis(const float* P, const float* s, float* result, int64_t
 // ------------------------------------------------------------------------------------------
 //  lq_batch: host object + C ABI
 // ------------------------------------------------------------------------------------------
+struct lq_task_table {                    // one device-resident task table
+    std::vector<lq::Task> h;
+    std::vector<int> index;               // table position -> descriptor index (tasks are ordered by work per block)
+    lq::Task* d = nullptr;
+    uint32_t* prefix_d = nullptr;         // [n] first block of every task, then [n] first group
+    uint32_t blocks = 0, groups = 0;
+    bool has_tile = false;                // some task runs the conv tile (needs the tile kernel's LDS)
+    int64_t ws_words = 0;
+};
+
 struct lq_batch {
     int n = 0;
-    std::vector<lq::Task> fwd_h, bwd_h, pen_h;
-    std::vector<int> bwd_index;          // bwd task -> descriptor index
+    lq_task_table fwd, bwd, pen;          // pen: every tensor, with workspace slices and mb/ties buffers (penalty passes)
     std::vector<lq::AdamTask> adam_h;
-    lq::Task* fwd_d = nullptr;
-    lq::Task* bwd_d = nullptr;
-    lq::Task* pen_d = nullptr;           // every tensor, with workspace slices and mb/ties buffers (penalty passes)
     float* mb_d = nullptr;
     uint32_t* ties_d = nullptr;
     lq::AdamTask* adam_d = nullptr;
-    uint32_t fwd_blocks = 0, bwd_blocks = 0, bwd_groups = 0, pen_blocks = 0, pen_groups = 0;
     size_t ws_bytes = 256;
     bool has_perm = false;               // some conv kernel has an OIHW companion
 };
 
 namespace lq {
 
-static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, uint32_t& block_prefix, uint32_t& group_prefix, int64_t& ws_words) {
+// Conv-tile geometry of an HWIO kernel (lq_conv_tile.hpp), or false when the tensor keeps the generic traversal: kernels
+// with more than 9 taps, co % 4 != 0, or a descriptor whose groups are not a function of (h, c) the tile knows.
+static bool make_conv_tile(ConvTile& ct, int64_t hw, int64_t ci, int64_t co, int64_t outer, int64_t G, int64_t inner) {
+    memset(&ct, 0, sizeof(ct));
+    if (hw < 1 || hw > kCtPass || co % 4 != 0 || ci < 1) return false;
+    if ((double)hw * (double)ci * (double)co >= 4294967296.0) return false;
+    int kind;
+    int64_t A = 1;
+    if (G == 1) {
+        kind = 1;
+        A = hw;
+    } else if (inner == co && G == ci) {
+        kind = 0;
+    } else if (inner % (ci * co) == 0 && G <= 255) {
+        kind = 1;
+        A = inner / (ci * co);
+        if (outer * G * A != hw) return false;
+    } else {
+        return false;
+    }
+    int64_t m = kCtPass / hw;
+    const int64_t mc = ceil_div(ci, 32);
+    if (m > mc) m = mc;
+    if (m < 1) m = 1;
+    ct.hw = (uint32_t)hw;
+    ct.ci = (uint32_t)ci;
+    ct.co = (uint32_t)co;
+    ct.tc = (uint32_t)(32 * m);
+    ct.ntc = (uint32_t)ceil_div(ci, 32 * m);
+    ct.nto = (uint32_t)ceil_div(co, kCtO);
+    if ((double)ct.ntc * (double)ct.nto > 2147483647.0) return false;
+    ct.npass = (uint32_t)(m * hw);
+    ct.kind = (uint32_t)kind;
+    ct.fnto = make_fastdiv(ct.nto);
+    ct.frun = make_fastdiv((uint32_t)(32 * m * hw));
+    const int64_t tc_last = ci - (int64_t)(ct.ntc - 1) * 32 * m;
+    ct.frun_edge = make_fastdiv((uint32_t)(tc_last * hw));
+    // pass order: kind 0 by channel block, kind 1 group by group (one accumulator flush per group)
+    struct PassKey { int g, j, h; };
+    std::vector<PassKey> ps;
+    for (int64_t j = 0; j < m; ++j)
+        for (int64_t h = 0; h < hw; ++h) ps.push_back({kind == 0 ? (int)j : (int)((h / A) % G), (int)j, (int)h});
+    std::stable_sort(ps.begin(), ps.end(), [](const PassKey& a, const PassKey& b) { return a.g < b.g; });
+    for (size_t q = 0; q < ps.size(); ++q) {
+        ct.pass_c[q] = (uint16_t)(32 * ps[q].j);
+        ct.pass_h[q] = (uint8_t)ps[q].h;
+        ct.pass_g[q] = (uint8_t)(kind == 0 ? 0 : ps[q].g);
+        ct.pass_new[q] = (uint8_t)(q > 0 && ps[q].g != ps[q - 1].g);
+    }
+    return true;
+}
+
+static int64_t conv_tile_partials(const ConvTile& ct, int64_t G) {
+    return ct.kind == 0 ? (int64_t)ct.ci * ct.nto : G * (int64_t)ct.nto * ct.ntc * kWavesPerBlock;
+}
+
+// finalize geometry of the tile's partials (see ct_flush)
+static void conv_tile_fin(const ConvTile& ct, int64_t G, int64_t& gstride, int64_t& n1, int64_t& stride1, int64_t& n2) {
+    n1 = 1;
+    stride1 = 0;
+    n2 = ct.kind == 0 ? (int64_t)ct.nto : (int64_t)ct.nto * ct.ntc * kWavesPerBlock;
+    gstride = n2;
+    (void)G;
+}
+
+static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, bool allow_tile, lq_task_table& tb) {
     memset(&t, 0, sizeof(t));
     const Plan pl = make_plan(d.outer, d.G, d.inner, kBlock);
     t.p = base_params(d.P, d.s, d.outer, d.G, d.inner);
@@ -1229,15 +1374,18 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, uint32_t& block
     t.p.dy = d.dy;
     t.p.lam = d.lambda;
     t.p.tmode = (d.lambda < 4.0e-4f) ? 0 : ((d.lambda <= 0.25f) ? 1 : 2);
+    bool tile = false;
     if (d.conv_co > 0) {
         t.p.out_perm = bwd ? nullptr : d.out_oihw;
         t.p.perm_hw = (uint32_t)d.conv_hw;
         t.p.perm_ci = (uint32_t)d.conv_ci;
         t.p.perm_co = (uint32_t)d.conv_co;
         t.dp = d.dp;
+        tile = allow_tile && aligned(d.P, 16) && aligned(bwd ? (const void*)d.dp : (const void*)d.out, 16) &&
+               make_conv_tile(t.ct, d.conv_hw, d.conv_ci, d.conv_co, d.outer, d.G, d.inner);
     }
     t.ds = d.ds;
-    t.mode = pl.mode;
+    t.mode = tile ? MODE_CONV_TILE : pl.mode;
     t.lpr_log2 = pl.lpr_log2;
     t.R = pl.R;
     t.L = pl.L;
@@ -1245,9 +1393,12 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, uint32_t& block
     t.C = pl.C;
     t.rps = pl.rps;
     t.nbx = 0;
-    if (pl.mode == MODE_COL) col_variant(pl, d.P, nullptr, bwd ? nullptr : d.out, t.col_variant, t.nbx, false);
+    if (!tile && pl.mode == MODE_COL) col_variant(pl, d.P, nullptr, bwd ? nullptr : d.out, t.col_variant, t.nbx, false);
     int64_t blocks;
-    if (pl.mode == MODE_ROW_BIG) {
+    if (tile) {
+        blocks = (int64_t)t.ct.ntc * t.ct.nto;
+        t.vec = 1;
+    } else if (pl.mode == MODE_ROW_BIG) {
         blocks = pl.R * pl.nc;
         // float4 path: forward needs P and out 16-byte aligned; backward needs P (dy is checked at every launch)
         t.vec = (aligned(d.P, 16) && (bwd || aligned(d.out, 16))) ? 1 : 0;
@@ -1258,24 +1409,84 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, uint32_t& block
     } else {
         blocks = t.nbx * pl.ysplit;
     }
-    if (blocks <= 0 || blocks > 0x7fffffffll || (uint64_t)block_prefix + (uint64_t)blocks > 0xffffffffull)
-        return fail(LQ_EINVAL, "lq_batch_create: too many blocks");
-    t.first_block = block_prefix;
-    block_prefix += (uint32_t)blocks;
-    t.first_group = group_prefix;
+    if (blocks <= 0 || blocks > 0x7fffffffll) return fail(LQ_EINVAL, "lq_batch_create: too many blocks");
+    t.first_block = (uint32_t)blocks;            // block COUNT until finish_table() turns it into a prefix
     if (bwd) {
-        if ((uint64_t)group_prefix + (uint64_t)d.G > 0xffffffffull) return fail(LQ_EINVAL, "lq_batch_create: too many groups");
-        group_prefix += (uint32_t)d.G;
-        t.np_pad = (pl.np + 63) / 64 * 64;
-        t.ws_off = ws_words;
-        ws_words += 3 * t.np_pad;
+        t.first_group = (uint32_t)d.G;           // likewise
+        int64_t np = pl.np;
         t.gstride = pl.gstride;
         t.n1 = pl.n1;
         t.stride1 = pl.stride1;
         t.n2 = pl.n2;
+        if (tile) {
+            np = conv_tile_partials(t.ct, d.G);
+            conv_tile_fin(t.ct, d.G, t.gstride, t.n1, t.stride1, t.n2);
+        }
+        t.np_pad = (np + 63) / 64 * 64;
         t.count = (double)d.outer * (double)d.inner;
     }
+    if (tile) tb.has_tile = true;
     return LQ_OK;
+}
+
+// Orders the table by decreasing work per block (tiles first), assigns block / group prefixes and workspace slices, uploads.
+static int finish_table(lq_task_table& tb, bool bwd) {
+    const size_t n = tb.h.size();
+    if (!n) return LQ_OK;
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = i;
+    auto weight = [&](size_t i) {
+        const Task& t = tb.h[i];
+        const double el = (double)t.p.outer * (double)t.p.G * (double)t.p.inner;
+        return el / (double)t.first_block;                     // elements per block
+    };
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight(a) > weight(b); });
+    std::vector<Task> h2(n);
+    std::vector<int> idx2(n);
+    std::vector<uint32_t> prefix(2 * n);
+    uint64_t bp = 0, gp = 0;
+    int64_t words = 0;
+    for (size_t k = 0; k < n; ++k) {
+        Task t = tb.h[order[k]];
+        const uint32_t nb = t.first_block, ng = bwd ? t.first_group : 0u;
+        if (bp + nb > 0xffffffffull || gp + ng > 0xffffffffull) return fail(LQ_EINVAL, "lq_batch_create: too many blocks or groups");
+        t.first_block = (uint32_t)bp;
+        t.first_group = (uint32_t)gp;
+        prefix[k] = (uint32_t)bp;
+        prefix[n + k] = (uint32_t)gp;
+        bp += nb;
+        gp += ng;
+        if (bwd) {
+            t.ws_off = words;
+            words += 4 * t.np_pad;
+        }
+        h2[k] = t;
+        idx2[k] = tb.index[order[k]];
+    }
+    tb.h.swap(h2);
+    tb.index.swap(idx2);
+    tb.blocks = (uint32_t)bp;
+    tb.groups = (uint32_t)gp;
+    tb.ws_words = words;
+    hipError_t e = hipMalloc(&tb.prefix_d, 2 * n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(tb.prefix_d, prefix.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&tb.d, n * sizeof(Task));
+    if (e != hipSuccess) return fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
+    return LQ_OK;
+}
+
+static int upload_table(lq_task_table& tb) {
+    if (tb.h.empty()) return LQ_OK;
+    hipError_t e = hipMemcpy(tb.d, tb.h.data(), tb.h.size() * sizeof(Task), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
+    return LQ_OK;
+}
+
+static void free_table(lq_task_table& tb) {
+    if (tb.d) (void)hipFree(tb.d);
+    if (tb.prefix_d) (void)hipFree(tb.prefix_d);
+    tb.d = nullptr;
+    tb.prefix_d = nullptr;
 }
 
 }  // namespace lq
@@ -1288,11 +1499,10 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
     lq_batch* b = new (std::nothrow) lq_batch();
     if (!b) return fail(LQ_EHIP, "lq_batch_create: out of host memory");
     b->n = n;
-    int64_t ws_words = 0, dummy = 0, pen_words = 0;
-    uint32_t gp_dummy = 0;
-    for (int i = 0; i < n; ++i) {
+    int rc = LQ_OK;
+    for (int i = 0; i < n && !rc; ++i) {
         const lq_tensor_desc& d = descs[i];
-        int rc = check_desc(d.outer, d.G, d.inner);
+        rc = check_desc(d.outer, d.G, d.inner);
         if (!rc && (!d.P || !d.s || !d.out)) rc = fail(LQ_EINVAL, "lq_batch_create: tensor %d has a NULL P/s/out", i);
         if (!rc && (!aligned(d.P, 4) || !aligned(d.s, 4) || !aligned(d.out, 4))) rc = fail(LQ_EALIGN, "lq_batch_create: tensor %d misaligned", i);
         if (!rc && d.conv_co > 0) {
@@ -1302,34 +1512,25 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
             if (!rc) b->has_perm = true;
         }
         Task t;
-        if (!rc) rc = fill_task(t, d, false, b->fwd_blocks, gp_dummy, dummy);
-        if (rc) {
-            delete b;
-            return rc;
-        }
-        b->fwd_h.push_back(t);
+        if (!rc) rc = fill_task(t, d, false, true, b->fwd);
+        if (rc) break;
+        b->fwd.h.push_back(t);
+        b->fwd.index.push_back(i);
         if (d.ds) {                   // penalty passes need a scale-gradient destination
             Task tp;
-            rc = fill_task(tp, d, true, b->pen_blocks, b->pen_groups, pen_words);
-            if (rc) {
-                delete b;
-                return rc;
-            }
-            b->pen_h.push_back(tp);
+            if ((rc = fill_task(tp, d, true, false, b->pen))) break;
+            b->pen.h.push_back(tp);
+            b->pen.index.push_back(i);
         }
         if (d.lambda == d.lambda) {   // not NaN: nested-quantization tensor with a scale gradient
             if (!d.ds) {
-                delete b;
-                return fail(LQ_EINVAL, "lq_batch_create: tensor %d has lambda but no ds", i);
+                rc = fail(LQ_EINVAL, "lq_batch_create: tensor %d has lambda but no ds", i);
+                break;
             }
             Task tb;
-            rc = fill_task(tb, d, true, b->bwd_blocks, b->bwd_groups, ws_words);
-            if (rc) {
-                delete b;
-                return rc;
-            }
-            b->bwd_h.push_back(tb);
-            b->bwd_index.push_back(i);
+            if ((rc = fill_task(tb, d, true, true, b->bwd))) break;
+            b->bwd.h.push_back(tb);
+            b->bwd.index.push_back(i);
         }
         if (d.m && d.v) {
             AdamTask a;
@@ -1341,50 +1542,51 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
             a.n = d.G;
             a.min_value = d.min_value;
             if (!d.ds) {
-                delete b;
-                return fail(LQ_EINVAL, "lq_batch_create: tensor %d has Adam state but no ds", i);
+                rc = fail(LQ_EINVAL, "lq_batch_create: tensor %d has Adam state but no ds", i);
+                break;
             }
             b->adam_h.push_back(a);
         }
     }
-    b->ws_bytes = (size_t)(ws_words > pen_words ? ws_words : pen_words) * 4 + 256;
-    hipError_t e = hipMalloc(&b->fwd_d, b->fwd_h.size() * sizeof(Task));
-    if (e == hipSuccess) e = hipMemcpy(b->fwd_d, b->fwd_h.data(), b->fwd_h.size() * sizeof(Task), hipMemcpyHostToDevice);
-    if (e == hipSuccess && !b->bwd_h.empty()) {
-        e = hipMalloc(&b->bwd_d, b->bwd_h.size() * sizeof(Task));
-        if (e == hipSuccess) e = hipMemcpy(b->bwd_d, b->bwd_h.data(), b->bwd_h.size() * sizeof(Task), hipMemcpyHostToDevice);
-    }
-    if (e == hipSuccess && !b->pen_h.empty()) {
-        e = hipMalloc(&b->mb_d, (size_t)b->pen_groups * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(&b->ties_d, (size_t)b->pen_groups * sizeof(uint32_t));
-        if (e == hipSuccess) {
-            for (auto& tp : b->pen_h) {
-                tp.mb = b->mb_d + tp.first_group;
-                tp.ties = b->ties_d + tp.first_group;
-            }
-            e = hipMalloc(&b->pen_d, b->pen_h.size() * sizeof(Task));
+    if (!rc) rc = finish_table(b->fwd, false);
+    if (!rc) rc = finish_table(b->bwd, true);
+    if (!rc) rc = finish_table(b->pen, true);
+    if (!rc && !b->pen.h.empty()) {
+        hipError_t e = hipMalloc(&b->mb_d, (size_t)b->pen.groups * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&b->ties_d, (size_t)b->pen.groups * sizeof(uint32_t));
+        if (e != hipSuccess) rc = fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
+        for (auto& tp : b->pen.h) {
+            tp.mb = b->mb_d + tp.first_group;
+            tp.ties = b->ties_d + tp.first_group;
         }
-        if (e == hipSuccess) e = hipMemcpy(b->pen_d, b->pen_h.data(), b->pen_h.size() * sizeof(Task), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess && !b->adam_h.empty()) {
-        e = hipMalloc(&b->adam_d, b->adam_h.size() * sizeof(AdamTask));
+    if (!rc) rc = upload_table(b->fwd);
+    if (!rc) rc = upload_table(b->bwd);
+    if (!rc) rc = upload_table(b->pen);
+    if (!rc && !b->adam_h.empty()) {
+        hipError_t e = hipMalloc(&b->adam_d, b->adam_h.size() * sizeof(AdamTask));
         if (e == hipSuccess) e = hipMemcpy(b->adam_d, b->adam_h.data(), b->adam_h.size() * sizeof(AdamTask), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
     }
-    if (e != hipSuccess) {
-        const int rc = fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
+    if (rc) {
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
         lq_batch_destroy(b);
+        memcpy(g_err, keep, sizeof(keep));
         return rc;
     }
+    const int64_t words = b->bwd.ws_words > b->pen.ws_words ? b->bwd.ws_words : b->pen.ws_words;
+    b->ws_bytes = (size_t)words * 4 + 256;
     *out = b;
     return LQ_OK;
 }
 
 int lq_batch_destroy(lq_batch* b) {
     if (!b) return LQ_OK;
-    if (b->fwd_d) (void)hipFree(b->fwd_d);
-    if (b->bwd_d) (void)hipFree(b->bwd_d);
+    free_table(b->fwd);
+    free_table(b->bwd);
+    free_table(b->pen);
     if (b->adam_d) (void)hipFree(b->adam_d);
-    if (b->pen_d) (void)hipFree(b->pen_d);
     if (b->mb_d) (void)hipFree(b->mb_d);
     if (b->ties_d) (void)hipFree(b->ties_d);
     delete b;
@@ -1397,12 +1599,14 @@ int lq_batch_forward(const lq_batch* b, void* stream) {
     if (!b) return fail(LQ_EINVAL, "lq_batch_forward: NULL batch");
     PtrPack pk;
     CoefPack cf;
+    const lq_task_table& tb = b->fwd;
+    const int nt = (int)tb.h.size();
     if (b->has_perm)
-        hipLaunchKernelGGL((k_batch_traverse<OP_FWD_PERM>), dim3(b->fwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->fwd_d,
-                           (int)b->fwd_h.size(), (uint32_t*)nullptr, pk, 0, cf);
+        hipLaunchKernelGGL((k_batch_traverse<OP_FWD_PERM>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.prefix_d, nt,
+                           (uint32_t*)nullptr, pk, 0, cf);
     else
-        hipLaunchKernelGGL((k_batch_traverse<OP_FWD>), dim3(b->fwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->fwd_d,
-                           (int)b->fwd_h.size(), (uint32_t*)nullptr, pk, 0, cf);
+        hipLaunchKernelGGL((k_batch_traverse<OP_FWD>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.prefix_d, nt,
+                           (uint32_t*)nullptr, pk, 0, cf);
     return check_hip("batch forward launch");
 }
 
@@ -1428,39 +1632,42 @@ int lq_batch_scale_grad_oihw(const lq_batch* b, const float* const* dy, void* ws
 
 static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream, bool oihw) {
     if (!b) return fail(LQ_EINVAL, "lq_batch_scale_grad: NULL batch");
-    if (b->bwd_h.empty()) return LQ_OK;
+    const lq_task_table& tb = b->bwd;
+    if (tb.h.empty()) return LQ_OK;
     if (!ws) return fail(LQ_EWORKSPACE, "lq_batch_scale_grad: workspace is NULL (need %zu bytes)", b->ws_bytes);
     if (!aligned(ws, 16)) return fail(LQ_EALIGN, "lq_batch_scale_grad: workspace must be 16-byte aligned");
     if (ws_bytes < b->ws_bytes) return fail(LQ_EWORKSPACE, "lq_batch_scale_grad: workspace too small: %zu < %zu bytes", ws_bytes, b->ws_bytes);
     PtrPack pk;
     memset(&pk, 0, sizeof(pk));
     bool all_aligned = true;
-    for (size_t i = 0; i < b->bwd_h.size(); ++i) {
-        const float* d = dy ? dy[b->bwd_index[i]] : b->bwd_h[i].p.dy;
-        if (!d) return fail(LQ_EINVAL, "lq_batch_scale_grad: no upstream gradient for tensor %d", b->bwd_index[i]);
-        if (!aligned(d, 4)) return fail(LQ_EALIGN, "lq_batch_scale_grad: dy of tensor %d misaligned", b->bwd_index[i]);
-        const bool gathered = oihw && b->bwd_h[i].p.perm_co != 0;      // read element-wise through the permutation: no vector loads
-        if (!gathered && ((b->bwd_h[i].mode != MODE_COL && b->bwd_h[i].vec) || (b->bwd_h[i].mode == MODE_COL && b->bwd_h[i].col_variant >= 4)) &&
-            !aligned(d, 16))
-            all_aligned = false;
+    for (size_t i = 0; i < tb.h.size(); ++i) {
+        const lq::Task& t = tb.h[i];
+        const float* d = dy ? dy[tb.index[i]] : t.p.dy;
+        if (!d) return fail(LQ_EINVAL, "lq_batch_scale_grad: no upstream gradient for tensor %d", tb.index[i]);
+        if (!aligned(d, 4)) return fail(LQ_EALIGN, "lq_batch_scale_grad: dy of tensor %d misaligned", tb.index[i]);
+        const bool gathered = oihw && t.p.perm_co != 0;      // read through the permutation (LDS tile or element-wise): no vector loads
+        const bool wants16 = t.mode == MODE_CONV_TILE || (t.mode != MODE_COL && t.vec) || (t.mode == MODE_COL && t.col_variant >= 4);
+        if (!gathered && wants16 && !aligned(d, 16)) all_aligned = false;
         pk.dy[i] = d;
     }
     if (!all_aligned) return fail(LQ_EALIGN, "lq_batch_scale_grad: a 16-byte aligned tensor got a dy that is not 16-byte aligned");
     CoefPack cf;
-    if (oihw)
-        hipLaunchKernelGGL((k_batch_traverse<OP_BWD_PERM>), dim3(b->bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->bwd_d,
-                           (int)b->bwd_h.size(), (uint32_t*)ws, pk, 3, cf);
+    const int nt = (int)tb.h.size();
+    // the kernel with the conv-tile LDS whenever a tile task is in the table (its generic bodies compute what OP_BWD's do)
+    if (oihw || tb.has_tile)
+        hipLaunchKernelGGL((k_batch_traverse<OP_BWD_PERM>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.prefix_d, nt,
+                           (uint32_t*)ws, pk, oihw ? 3 : 1, cf);
     else
-        hipLaunchKernelGGL((k_batch_traverse<OP_BWD>), dim3(b->bwd_blocks), dim3(kBlock), 0, (hipStream_t)stream, b->bwd_d,
-                           (int)b->bwd_h.size(), (uint32_t*)ws, pk, 1, cf);
+        hipLaunchKernelGGL((k_batch_traverse<OP_BWD>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.prefix_d, nt,
+                           (uint32_t*)ws, pk, 1, cf);
     int rc = check_hip("batch scale-grad launch");
     if (rc) return rc;
-    if (batch_wide_finalize(b->bwd_h))
-        hipLaunchKernelGGL((k_batch_finalize<OP_BWD, 256>), dim3(b->bwd_groups), dim3(256), 0, (hipStream_t)stream, b->bwd_d,
-                           (int)b->bwd_h.size(), (uint32_t*)ws, 0);
+    if (batch_wide_finalize(tb.h))
+        hipLaunchKernelGGL((k_batch_finalize<OP_BWD, 256>), dim3(tb.groups), dim3(256), 0, (hipStream_t)stream, tb.d, tb.prefix_d + nt, nt,
+                           (uint32_t*)ws, 0);
     else
-        hipLaunchKernelGGL((k_batch_finalize<OP_BWD>), dim3(b->bwd_groups), dim3(64), 0, (hipStream_t)stream, b->bwd_d,
-                           (int)b->bwd_h.size(), (uint32_t*)ws, 0);
+        hipLaunchKernelGGL((k_batch_finalize<OP_BWD>), dim3(tb.groups), dim3(64), 0, (hipStream_t)stream, tb.d, tb.prefix_d + nt, nt,
+                           (uint32_t*)ws, 0);
     return check_hip("batch finalize launch");
 }
 
@@ -1473,39 +1680,42 @@ int lq_batch_penalty_grads(const lq_batch* b, int kind, const float* coeff, floa
     kind &= ~LQ_PENALTY_ACCUMULATE_DS;
     if (kind < LQ_PENALTY_MAXBIN || kind > LQ_PENALTY_INVERSE) return fail(LQ_EINVAL, "lq_batch_penalty_grads: bad kind %d", kind);
     if (!coeff) return fail(LQ_EINVAL, "lq_batch_penalty_grads: coeff is NULL");
-    if (b->pen_h.size() != (size_t)b->n) return fail(LQ_EINVAL, "lq_batch_penalty_grads: every tensor of the batch needs a ds buffer");
+    const lq_task_table& tb = b->pen;
+    if (tb.h.size() != (size_t)b->n) return fail(LQ_EINVAL, "lq_batch_penalty_grads: every tensor of the batch needs a ds buffer");
     CoefPack cf;
     PtrPack pk;
     memset(&pk, 0, sizeof(pk));
     memset(&cf, 0, sizeof(cf));
-    for (int i = 0; i < b->n; ++i) cf.c[i] = coeff[i];
-    const int nt = (int)b->pen_h.size();
+    const int nt = (int)tb.h.size();
+    for (int i = 0; i < nt; ++i) cf.c[i] = coeff[tb.index[i]];
     hipStream_t st = (hipStream_t)stream;
     if (kind != LQ_PENALTY_INVERSE) {
         if (!grad) return fail(LQ_EINVAL, "lq_batch_penalty_grads: grad pointers are NULL");
         if (!ws) return fail(LQ_EWORKSPACE, "lq_batch_penalty_grads: workspace is NULL (need %zu bytes)", b->ws_bytes);
         if (!aligned(ws, 16)) return fail(LQ_EALIGN, "lq_batch_penalty_grads: workspace must be 16-byte aligned");
         if (ws_bytes < b->ws_bytes) return fail(LQ_EWORKSPACE, "lq_batch_penalty_grads: workspace too small: %zu < %zu bytes", ws_bytes, b->ws_bytes);
-        for (int i = 0; i < b->n; ++i) {
-            if (!grad[i] || !aligned(grad[i], 4)) return fail(LQ_EINVAL, "lq_batch_penalty_grads: gradient buffer of tensor %d missing", i);
-            const Task& t = b->pen_h[i];
+        for (int i = 0; i < nt; ++i) {
+            float* gi = grad[tb.index[i]];
+            if (!gi || !aligned(gi, 4)) return fail(LQ_EINVAL, "lq_batch_penalty_grads: gradient buffer of tensor %d missing", tb.index[i]);
+            const Task& t = tb.h[i];
             const bool wants16 = (t.mode != MODE_COL && t.vec) || (t.mode == MODE_COL && t.col_variant >= 4);
-            if (wants16 && !aligned(grad[i], 16)) return fail(LQ_EALIGN, "lq_batch_penalty_grads: gradient buffer of tensor %d is not 16-byte aligned", i);
-            pk.dy[i] = grad[i];
+            if (wants16 && !aligned(gi, 16)) return fail(LQ_EALIGN, "lq_batch_penalty_grads: gradient buffer of tensor %d is not 16-byte aligned", tb.index[i]);
+            pk.dy[i] = gi;
         }
     }
+    const uint32_t* gpre = tb.prefix_d + nt;
     if (kind == LQ_PENALTY_MAXBIN) {
         PtrPack none;
         memset(&none, 0, sizeof(none));
-        hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_FWD>), dim3(b->pen_blocks), dim3(kBlock), 0, st, b->pen_d, nt, (uint32_t*)ws, none, 0, cf);
-        hipLaunchKernelGGL((k_batch_finalize<OP_MAXBIN_FWD>), dim3(b->pen_groups), dim3(64), 0, st, b->pen_d, nt, (uint32_t*)ws, 0);
-        hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_BWD>), dim3(b->pen_blocks), dim3(kBlock), 0, st, b->pen_d, nt, (uint32_t*)ws, pk, 2, cf);
-        hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(b->pen_groups, kBlock)), dim3(kBlock), 0, st, b->pen_d, nt, b->pen_groups, 0, cf, accum);
+        hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_FWD>), dim3(tb.blocks), dim3(kBlock), 0, st, tb.d, tb.prefix_d, nt, (uint32_t*)ws, none, 0, cf);
+        hipLaunchKernelGGL((k_batch_finalize<OP_MAXBIN_FWD>), dim3(tb.groups), dim3(64), 0, st, tb.d, gpre, nt, (uint32_t*)ws, 0);
+        hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_BWD>), dim3(tb.blocks), dim3(kBlock), 0, st, tb.d, tb.prefix_d, nt, (uint32_t*)ws, pk, 2, cf);
+        hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(tb.groups, kBlock)), dim3(kBlock), 0, st, tb.d, gpre, nt, tb.groups, 0, cf, accum);
     } else if (kind == LQ_PENALTY_DIFFERENCE) {
-        hipLaunchKernelGGL((k_batch_traverse<OP_DIFF_BWD>), dim3(b->pen_blocks), dim3(kBlock), 0, st, b->pen_d, nt, (uint32_t*)ws, pk, 2, cf);
-        hipLaunchKernelGGL((k_batch_finalize<OP_DIFF_BWD>), dim3(b->pen_groups), dim3(64), 0, st, b->pen_d, nt, (uint32_t*)ws, accum);
+        hipLaunchKernelGGL((k_batch_traverse<OP_DIFF_BWD>), dim3(tb.blocks), dim3(kBlock), 0, st, tb.d, tb.prefix_d, nt, (uint32_t*)ws, pk, 2, cf);
+        hipLaunchKernelGGL((k_batch_finalize<OP_DIFF_BWD>), dim3(tb.groups), dim3(64), 0, st, tb.d, gpre, nt, (uint32_t*)ws, accum);
     } else {
-        hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(b->pen_groups, kBlock)), dim3(kBlock), 0, st, b->pen_d, nt, b->pen_groups, 2, cf, accum);
+        hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(tb.groups, kBlock)), dim3(kBlock), 0, st, tb.d, gpre, nt, tb.groups, 2, cf, accum);
     }
     return check_hip("batch penalty launch");
 }

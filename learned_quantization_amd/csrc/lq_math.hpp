@@ -79,7 +79,7 @@ __device__ __forceinline__ void nq_accumulate(float q, float o, float dy, float 
     const float ratio = a / b;                         // :64
     if (!(ratio >= lam)) {                             // :70 / :97 (NaN counts as "not above")
         acc.b += 1u;
-        acc.c -= abs_tanh(lam - ratio, tmode);         // :84 / :110
+        acc.c -= (double)abs_tanh(lam - ratio, tmode); // :84 / :110 (f64 sum: exact for tmode 0, see Acc)
     }
 }
 
@@ -151,7 +151,7 @@ __device__ __forceinline__ void vote_tally(float ratio, float lam, Acc& acc) {
     const bool below = !(ratio >= lam);                  // NaN counts as "not above"
     acc.b += below ? 1u : 0u;
     const float t = abs_tanh_t<TM>(lam - ratio);
-    acc.c -= below ? t : 0.0f;
+    acc.c -= (double)(below ? t : 0.0f);                 // f64 sum: exact for TM == 0, see Acc
 }
 
 template <int TM>

@@ -241,7 +241,7 @@ struct OpT<OP_DIFF_FWD> : OpBase {
     static constexpr bool kReduce = true;
     __device__ static __forceinline__ float elem(const Params&, const Ctx& c, int64_t, float x, float, Acc& acc) {
         float pq = x / c.s;                             // custom_loss_functions.py:172
-        acc.c += fabsf(x - pq);                         // :175
+        acc.c += (double)fabsf(x - pq);                 // :175
         return 0.f;
     }
 };
@@ -268,7 +268,7 @@ struct OpT<OP_DIFF_BWD> : OpBase {
         float u = x - pq;
         float sgn = (u > 0.f) ? 1.f : ((u < 0.f) ? -1.f : 0.f);
         float gi = sgn * c.k0;
-        acc.c += (gi * pq) / c.s;
+        acc.c += (double)((gi * pq) / c.s);
         const float g = gi - gi / c.s;
         return p.accum ? p.out[i] + g : g;
     }

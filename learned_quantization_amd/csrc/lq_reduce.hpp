@@ -68,10 +68,17 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
 template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)u);
+    const uint32_t hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(u >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void dpp_step(Acc& acc) {
     const uint32_t a = dpp_u32<CTRL, ROW_MASK>(0u, acc.a);
     const uint32_t b = dpp_u32<CTRL, ROW_MASK>(0u, acc.b);
-    const float c = __uint_as_float(dpp_u32<CTRL, ROW_MASK>(0u, __float_as_uint(acc.c)));
+    const double c = dpp_f64<CTRL, ROW_MASK>(acc.c);
     acc.a = a > acc.a ? a : acc.a;
     acc.b += b;
     acc.c += c;
@@ -93,7 +100,7 @@ template <int BS>
 __device__ __forceinline__ void block_reduce_dpp(Acc& acc) {
     constexpr int NW = BS / 64;
     __shared__ uint32_t sa[NW], sb[NW];
-    __shared__ float sc[NW];
+    __shared__ double sc[NW];
     dpp_wave_reduce(acc);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (lane == 63) {
@@ -106,7 +113,7 @@ __device__ __forceinline__ void block_reduce_dpp(Acc& acc) {
         Acc r;
         r.a = lane < NW ? sa[lane] : 0u;
         r.b = lane < NW ? sb[lane] : 0u;
-        r.c = lane < NW ? sc[lane] : 0.f;
+        r.c = lane < NW ? sc[lane] : 0.0;
         dpp_row_reduce(r);       // NW <= 16: one row holds every wave's partial
         acc = r;
     }

@@ -576,7 +576,7 @@ __device__ __forceinline__ void team_reduce_std(Acc& acc) {     // every lane of
 #pragma unroll
         for (int off = 16; off < (1 << LG); off <<= 1) {
             const uint32_t a = __shfl_xor(acc.a, off, 64), b = __shfl_xor(acc.b, off, 64);
-            const float c = __shfl_xor(acc.c, off, 64);
+            const double c = __shfl_xor(acc.c, off, 64);
             acc.a = a > acc.a ? a : acc.a;
             acc.b += b;
             acc.c += c;

@@ -587,7 +587,7 @@ __device__ __forceinline__ void emit_direct(const Params& p, int64_t g, const Ac
     AccW w;
     w.a = acc.a;
     w.b = (double)acc.b;
-    w.c = (double)acc.c;
+    w.c = acc.c;
     FinT<OP>::emit(p, f, g, w);        // same arithmetic as the finalize of a single partial: bit-identical outputs
 }
 
@@ -596,18 +596,11 @@ __device__ __forceinline__ AccW load_partial(const Params& p, int64_t idx) {
     AccW w;
     w.a = p.pa[idx];
     w.b = (double)p.pb[idx];
-    w.c = (double)p.pc[idx];
+    w.c = p.pc[idx];
     return w;
 }
 
 // DPP reduction of the wide standard accumulator (max, add, add); same lane pattern as dpp_wave_reduce.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const unsigned long long u = __double_as_longlong(v);
-    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)u);
-    const uint32_t hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(u >> 32));
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void dpp_step_w(AccW& acc) {
     const uint32_t a = dpp_u32<CTRL, ROW_MASK>(0u, acc.a);

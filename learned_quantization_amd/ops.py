@@ -247,7 +247,7 @@ def fq_scale_grad_oihw(kernel: torch.Tensor, scale: torch.Tensor, dy_oihw: torch
     outer, G, inner = _desc(p, s)
     ds = torch.empty_like(s)
     dP = torch.empty_like(p)
-    ws = _hip.workspace_for(p.device, outer, G, inner)
+    ws = _hip.workspace(p.device, lib.lq_conv_workspace_bytes(hw, ci, co, outer, G, inner))
     _hip.check(lib.lq_fq_scale_grad_oihw(_hip.ptr(p), _hip.ptr(s), _hip.ptr(d), float(penalty_threshold), _hip.ptr(ds),
                                          _hip.ptr(dP), _hip.ptr(ws), ws.numel(), hw, ci, co, outer, G, inner,
                                          _hip.stream_ptr(p.device)), "lq_fq_scale_grad_oihw")

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/lq_hip.h but not exported"
     assert declared == set(_hip.SIGNATURES), "python binding table and header disagree"
-    assert lib.lq_version() == 2
+    assert lib.lq_version() == 3
     assert lib.lq_status_string(-3) == b"LQ_EWORKSPACE"
 
 

@@ -36,6 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--only", default=None, help="config:orientation, e.g. mnist:columnwise")
+    ap.add_argument("--abi-only", action="store_true", help="time only the raw batch ABI (profiling runs)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
@@ -78,10 +79,23 @@ def main():
                 lib.lq_batch_scale_grad(batch._handle, ptrs, batch.ws.data_ptr(), batch.ws.numel(), sp)
                 lib.lq_batch_scale_adam(batch._handle, 1e-4, 0.9, 0.999, 1e-7, 1, None, 0, sp)
 
-            rows.append({"config": config, "orientation": orient, "tensors": len(batch.entries), "elements": n_el,
-                         "us_per_step_batched_abi": timed(batched_abi_only, args.steps, dev),
-                         "us_per_step_batched_autograd": timed(batched_step, args.steps, dev),
-                         "us_per_step_per_tensor": timed(per_tensor_step, args.steps, dev)})
+            # the training path proper: the convolutions consumed the OIHW companions, so MIOpen's weight gradients arrive in
+            # OIHW order and the scale-gradient launch gathers them (and writes dP back in HWIO order)
+            dys_o = [d.permute(3, 2, 0, 1).contiguous() if e.out_oihw is not None else d for e, d in zip(batch.entries, dys)]
+            ptrs_o = (ctypes.c_void_p * len(dys))(*[d.data_ptr() for d in dys_o])
+
+            def batched_abi_oihw():
+                lib.lq_batch_forward(batch._handle, sp)
+                lib.lq_batch_scale_grad_oihw(batch._handle, ptrs_o, batch.ws.data_ptr(), batch.ws.numel(), sp)
+                lib.lq_batch_scale_adam(batch._handle, 1e-4, 0.9, 0.999, 1e-7, 1, None, 0, sp)
+
+            row = {"config": config, "orientation": orient, "tensors": len(batch.entries), "elements": n_el,
+                   "us_per_step_batched_abi": timed(batched_abi_only, args.steps, dev),
+                   "us_per_step_batched_abi_oihw": timed(batched_abi_oihw, args.steps, dev)}
+            if not args.abi_only:
+                row["us_per_step_batched_autograd"] = timed(batched_step, args.steps, dev)
+                row["us_per_step_per_tensor"] = timed(per_tensor_step, args.steps, dev)
+            rows.append(row)
             print(json.dumps(rows[-1]), flush=True)
             del batch, model
 
