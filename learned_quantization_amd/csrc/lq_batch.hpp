@@ -36,8 +36,9 @@ struct Task {
     uint32_t first_group;     // prefix over groups
 };
 
-// prefix[i] = first block (or first group) of task i, one contiguous array: the 5-7 probes of the search stay inside one or
-// two cache lines (probing the 400-byte task records themselves cost a cache miss per probe at the head of every block)
+// Traversal blocks find their task in a per-block table (one 2-byte load; a search costs 5-7 dependent loads at the head of
+// every block, before its first streaming load can be issued).  Groups and Adam blocks search the contiguous prefix array:
+// prefix[i] = first group of task i.
 __device__ __forceinline__ int find_task(const uint32_t* __restrict__ prefix, int ntasks, uint32_t b) {
     int lo = 0, hi = ntasks - 1;
     while (lo < hi) {
@@ -62,13 +63,15 @@ struct CoefPack {           // per-tensor upstream coefficient of a penalty term
 //           2 = penalty pass: pk.dy[] are the gradient buffers to ACCUMULATE into, cf.c[] the upstream coefficients;
 //           3 = as 1, but the gradients of conv kernels with an OIHW companion arrive in OIHW order (OP_BWD_PERM)
 template <int OP>
-__global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restrict__ tasks, const uint32_t* __restrict__ prefix, int ntasks,
+__global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restrict__ tasks, const uint16_t* __restrict__ block_task, int ntasks,
                                                            uint32_t* ws, PtrPack pk, int use_pack, CoefPack cf) {
     // one LDS scratch: the column traversal's accumulators, or the transposed tile of a conv kernel
     constexpr int kColBytes = OpT<OP>::kReduce ? kBlock * 4 * (int)sizeof(Acc) : 16;
-    constexpr int kTileBytes = (OP == OP_FWD_PERM || OP == OP_BWD_PERM) ? kCtLdsWords * 4 : 16;
+    constexpr int kTileBytes = OP == OP_FWD_PERM ? kCtLdsWordsFwd * 4 : (OP == OP_BWD_PERM ? kCtLdsWordsBwd * 4 : 16);
     __shared__ __align__(16) unsigned char smem[kColBytes > kTileBytes ? kColBytes : kTileBytes];
-    const int ti = find_task(prefix, ntasks, blockIdx.x);
+    LQ_TRACE(0);
+    const int ti = (int)block_task[blockIdx.x];
+    (void)ntasks;
     const Task& t = tasks[ti];
     Params p = t.p;
     if (use_pack == 1) p.dy = pk.dy[ti];
@@ -96,9 +99,8 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
     if (t.mode == MODE_CONV_TILE) {
         if constexpr (OP == OP_FWD_PERM) {
             conv_tile_fwd(p, t.ct, b, reinterpret_cast<float*>(smem));
-        } else if constexpr (OP == OP_BWD_PERM) {
-            if (p.dy_perm) conv_tile_bwd<true>(p, t.ct, b, reinterpret_cast<float*>(smem));
-            else conv_tile_bwd<false>(p, t.ct, b, reinterpret_cast<float*>(smem));
+        } else if constexpr (OP == OP_BWD_PERM) {        // every tile task has an OIHW companion: its gradient arrives in OIHW order
+            conv_tile_bwd(p, t.ct, b, reinterpret_cast<float*>(smem));
         }
     } else if (t.mode == 0) {
         const uint32_t nc = (uint32_t)t.nc;
@@ -112,6 +114,11 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
     } else {
         col_body<OP, false>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b, t.n1, reinterpret_cast<Acc*>(smem));
     }
+#ifdef LQ_DEV_KNOBS
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0);
+    LQ_TRACE(1);
+#endif
 }
 
 template <int OP, int BS = 64>     // BS = 256 when some group of the batch has more than 256 partials (host decides)

@@ -12,11 +12,14 @@
 // line (32 consecutive o).  In OIHW it sits at ((o ci + c) hw + h): for every o the tile holds ONE contiguous run of
 // 32 m hw floats (1152 bytes = 9 whole lines for a 3x3 kernel).  Both sides are therefore read and written in whole lines:
 //
-//   HWIO side   thread (c_l = t / 8, o4 = t % 8) owns the float4 at o0 + 4 o4 of row (h, c0 + 32 j + c_l) in pass p = (j, h);
-//               every pass's loads are issued up front (<= 9 passes, all independent);
-//   LDS         the tile transposed: word [o_l][k], k = (c - c0) hw + h, row stride 289 (odd): the 4-byte transposed
-//               accesses of a wave (8 channels x 8 float4 columns) and the run-order accesses are both conflict-free;
-//   OIHW side   thread t walks the tile's runs in run order, e = t + 256 i: consecutive lanes -> consecutive addresses.
+//   HWIO side   wave w owns the 8 m channels [8 m w, 8 m (w + 1)) of the tile; its lane (c_lw = lane / 8, o4 = lane % 8) owns the
+//               float4 at o0 + 4 o4 of row (h, c) in pass p = (j, h), c = c0 + 8 m w + 8 j + c_lw; every pass's loads are
+//               issued up front (<= 9 passes, all independent);
+//   LDS         per WAVE, no block barrier (a wave's LDS accesses execute in order): its slice transposed, word [o_l][k],
+//               k = (c - first channel of the wave) hw + h < 72, row stride 73 (odd): the 4-byte transposed accesses of a
+//               wave (8 channels x 8 float4 columns) and the run-order accesses are both conflict-free;
+//   OIHW side   the wave walks its runs (72 floats = 288 bytes per o; the block's four waves together cover the 1152-byte
+//               run of the tile) in run order, e = lane + 64 i: consecutive lanes -> consecutive addresses.
 //
 // K1 writes `out` from registers and the companion through LDS; K2 takes dy from the OIHW gradient through LDS (or, for the
 // plain entry points, from an HWIO gradient directly), writes dP in HWIO order and accumulates the vote.  The group of an
@@ -31,219 +34,290 @@
 
 namespace lq {
 
+// development builds (make dev): lq_dev_set_ablate(mask) switches parts of the tile kernels off, to see what each costs
+// (1: the element arithmetic, 2: the OIHW side, 4: the HWIO stores, 8: flush / partial stores).  Compiled out of the product.
+#ifdef LQ_DEV_KNOBS
+__device__ int g_ablate = 0;
+#define LQ_ABLATE(bit) ((g_ablate & (bit)) != 0)
+// lq_dev_set_trace(buf): every block of a batch traversal records wall_clock64() (100 MHz) at its start and end in
+// buf[2 * blockIdx.x], buf[2 * blockIdx.x + 1], and its XCC / CU / SIMD id word in buf's second half -- the block timeline
+__device__ unsigned long long* g_trace = nullptr;
+#define LQ_TRACE(slot) do { if (g_trace && threadIdx.x == 0) g_trace[2 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+#else
+#define LQ_ABLATE(bit) false
+#define LQ_TRACE(slot) do { } while (0)
+#endif
+
 constexpr int kCtO = 32;                       // output channels per tile
-constexpr int kCtRun = 288;                    // (c, h) pairs per tile: 32 m hw <= 288
-constexpr int kCtStride = kCtRun + 1;          // LDS row stride in words (odd)
 constexpr int kCtPass = 9;                     // passes of the HWIO side: m hw <= 9
-constexpr int kCtIter = kCtO * kCtRun / kBlock;   // 36 run-order steps of the OIHW side
-constexpr int kCtLdsWords = kCtO * kCtStride;  // 9248 words = 36 992 bytes
+constexpr int kCtRunW = 72;                    // (c, h) pairs per wave: 8 m hw <= 72
+constexpr int kCtStrideW = kCtRunW + 1;        // LDS row stride in words (odd: the transposed accesses are conflict-free)
+constexpr int kCtFwdStage = 8;                 // K1 stages 8 output channels at a time: 4 waves x 8 x 73 words = 9.3 KB per block
+constexpr int kCtLdsWordsFwd = kWavesPerBlock * kCtFwdStage * kCtStrideW;
+constexpr int kCtLdsWordsBwd = kWavesPerBlock * kCtO * kCtStrideW;          // K2 (OIHW gradient): the wave's whole tile, 37 KB per block
 
 struct ConvTile {
     uint32_t hw, ci, co;
-    uint32_t tc;                // input channels per tile (32 m)
+    uint32_t tc;                // input channels per tile (32 m): wave w owns channels [8 m w, 8 m (w + 1)) of it
     uint32_t nto, ntc;          // tiles along co / along ci
     uint32_t npass;             // m hw
     uint32_t kind;              // 0: g = c, 1: g = pass_g[p]
     FastDiv fnto;               // block -> (c-tile, o-tile)
-    FastDiv frun, frun_edge;    // run length tc_eff * hw of a full / of the last c-tile
-    uint16_t pass_c[kCtPass + 1];   // channel offset of pass p inside the tile (multiple of 32)
-    uint8_t pass_h[kCtPass + 1];    // h of pass p
-    uint8_t pass_g[kCtPass + 1];    // kind 1: group of pass p
-    uint8_t pass_new[kCtPass + 1];  // the group of pass p differs from that of pass p - 1 (flush the accumulator before it)
+    // Per-pass tables, one DWORD per entry: the rolled loop of K2 indexes them with its (uniform) pass counter, which must
+    // compile to scalar loads (lgkmcnt).  Sub-dword entries are fetched with VECTOR loads followed by s_waitcnt vmcnt(0) --
+    // a wait for every tile load in flight, once per pass.
+    uint32_t pass_info[kCtPass + 1];    // bits 0-7 pass_c (channel offset inside the wave's slice, multiple of 8), 8-15 pass_h,
+                                        // 16-23 pass_g (kind 1: group of the pass), 24 pass_new (group differs from pass p - 1: flush)
+    uint32_t pass_off[kCtPass + 1];     // (pass_h ci + pass_c) co: HWIO offset of pass p relative to the lane's first row
 };
+__device__ __forceinline__ uint32_t ct_pass_c(const ConvTile& ct, int q) { return ct.pass_info[q] & 0xffu; }
+__device__ __forceinline__ uint32_t ct_pass_h(const ConvTile& ct, int q) { return (ct.pass_info[q] >> 8) & 0xffu; }
+__device__ __forceinline__ uint32_t ct_pass_g(const ConvTile& ct, int q) { return (ct.pass_info[q] >> 16) & 0xffu; }
+__device__ __forceinline__ bool ct_pass_new(const ConvTile& ct, int q) { return (ct.pass_info[q] >> 24) != 0u; }
+__device__ __forceinline__ uint32_t ct_pass_k(const ConvTile& ct, int q) { return ct_pass_c(ct, q) * ct.hw + ct_pass_h(ct, q); }
 
 struct CtGeom {             // what a thread needs to know about its tile
-    uint32_t c0, o0, tc_eff, to_eff, c_l, o4, tile, to;
+    uint32_t c0, o0, tc_eff, to_eff, to, tile;
+    uint32_t w, lane, c_lw, o4;     // wave, lane, channel row of the lane inside a pass (0..7), float4 column (0..7)
+    uint32_t wc0, cw, RLw, M;       // first channel of the wave's slice (relative to c0), its channel count, run length cw * hw, magic
     bool ov;
 };
 
 __device__ __forceinline__ CtGeom ct_geom(const ConvTile& ct, uint32_t b) {
     CtGeom g;
     const uint32_t tci = fd_div(ct.fnto, b);
-    g.to = b - tci * ct.nto;
+    // o-tile rotated by the c-tile index: consecutive blocks go to consecutive XCDs, and with nto a multiple of 8 an XCD would
+    // otherwise only ever see o-tiles x and x + 8 -- two of the 16 values of (address / 128) % 16 in its L2
+    g.to = b - tci * ct.nto + tci;
+    g.to = g.to >= ct.nto ? g.to - ct.nto * fd_div(ct.fnto, g.to) : g.to;
     g.tile = b;
     g.c0 = tci * ct.tc;
     g.o0 = g.to * kCtO;
     g.tc_eff = ct.ci - g.c0 < ct.tc ? ct.ci - g.c0 : ct.tc;
     g.to_eff = ct.co - g.o0 < (uint32_t)kCtO ? ct.co - g.o0 : (uint32_t)kCtO;
-    g.c_l = threadIdx.x >> 3;
-    g.o4 = threadIdx.x & 7;
+    g.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    g.lane = threadIdx.x & 63;
+    g.c_lw = g.lane >> 3;
+    g.o4 = g.lane & 7;
     g.ov = 4 * g.o4 < g.to_eff;
+    const uint32_t m8 = ct.tc >> 2;
+    g.wc0 = g.w * m8;
+    g.cw = g.tc_eff > g.wc0 ? (g.tc_eff - g.wc0 < m8 ? g.tc_eff - g.wc0 : m8) : 0u;
+    g.RLw = g.cw * ct.hw;
+    // e / RLw for e < 32 * 72 as (e * M) >> 20 with M = floor(2^20 / RLw) + 1: exact while e * RLw < 2^20 (2304 * 72 = 165 888)
+    g.M = g.RLw ? (1u << 20) / g.RLw + 1u : 0u;
     return g;
 }
 
-// run-order index e of the tile -> (o_l, k); RL = tc_eff * hw
-__device__ __forceinline__ void ct_run(const ConvTile& ct, const CtGeom& g, uint32_t e, uint32_t& o_l, uint32_t& k) {
-    const bool edge = g.tc_eff != ct.tc;            // block-uniform
-    o_l = edge ? fd_div(ct.frun_edge, e) : fd_div(ct.frun, e);
-    k = e - o_l * (g.tc_eff * ct.hw);
-}
-
 // ------------------------------------------------------------------------------------------
-//  K1 on a tile: out (HWIO) from registers, out_perm (OIHW) through LDS when p.out_perm is set.
+//  K1 on a tile: out (HWIO) from registers, out_perm (OIHW) through the wave's LDS slice when p.out_perm is set.
+//  No block barrier: a wave transposes its own 8 m channels (LDS executes a wave's accesses in order), kCtFwdStage output
+//  channels at a time.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void conv_tile_fwd(const Params& p, const ConvTile& ct, uint32_t b, float* lds) {
     using O = OpT<OP_FWD>;
     const CtGeom g = ct_geom(ct, b);
+    // Every load is UNCONDITIONAL: a lane without an element in pass q re-reads the tile's first float4 (always in bounds,
+    // never used).  Predicated loads compile to branches with s_waitcnt vmcnt(0) between them -- one memory round trip per
+    // load instead of one per tile.
     float4 x[kCtPass];
-    uint32_t idx[kCtPass], crel[kCtPass];
     bool v[kCtPass];
+    const uint32_t idx_safe = g.c0 * ct.co + g.o0;
 #pragma unroll
     for (int q = 0; q < kCtPass; ++q) {
-        crel[q] = ct.pass_c[q] + g.c_l;
-        v[q] = q < (int)ct.npass && crel[q] < g.tc_eff && g.ov;
-        idx[q] = ((uint32_t)ct.pass_h[q] * ct.ci + g.c0 + crel[q]) * ct.co + g.o0 + 4 * g.o4;
-        x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (v[q]) x[q] = load4<0>(p.P + idx[q]);
+        const uint32_t crel = g.wc0 + ct_pass_c(ct, q) + g.c_lw;
+        v[q] = q < (int)ct.npass && crel < g.tc_eff && g.ov;
+        const uint32_t idx = (ct_pass_h(ct, q) * ct.ci + g.c0 + crel) * ct.co + g.o0 + 4 * g.o4;
+        x[q] = load4<0>(p.P + (v[q] ? idx : idx_safe));
     }
-    __builtin_amdgcn_sched_barrier(0);            // every load of the tile is in flight before the first scale fetch
+    // the scale of every pass is fetched NOW, with the tile's loads: fetched inside the pass loop, each new channel block of a
+    // 1x1 kernel (m = 9: nine different channels per lane) stalled the wave for a memory round trip
+    float sc[kCtPass];
+#pragma unroll
+    for (int q = 0; q < kCtPass; ++q) {
+        const uint32_t gq = ct.kind == 0 ? g.c0 + g.wc0 + ct_pass_c(ct, q) + g.c_lw : ct_pass_g(ct, q);
+        sc[q] = p.s[v[q] ? gq : 0u];
+    }
+    __builtin_amdgcn_sched_barrier(0);            // every load of the tile is in flight before the first use
     Acc none = O::template init<Acc>();
-    Ctx ctx = O::ctx(p, 0);
-    uint32_t gprev = 0;
+    Ctx ctx = O::ctx_of(p, 1.0f);
 #pragma unroll
     for (int q = 0; q < kCtPass; ++q) {
         if (q < (int)ct.npass) {                    // block-uniform
             if (v[q]) {
-                const uint32_t gq = ct.kind == 0 ? g.c0 + crel[q] : (uint32_t)ct.pass_g[q];
-                if (gq != gprev) {
-                    ctx = O::ctx(p, gq);
-                    gprev = gq;
-                }
-                const float4 o = O::elem4(p, ctx, idx[q], x[q], x[q], none);
-                store4<0>(p.out + idx[q], o);
-                if (p.out_perm) {
-                    float* w = lds + (4 * g.o4) * kCtStride + crel[q] * ct.hw + ct.pass_h[q];
-                    w[0] = o.x;
-                    w[kCtStride] = o.y;
-                    w[2 * kCtStride] = o.z;
-                    w[3 * kCtStride] = o.w;
-                }
+                const uint32_t crel = g.wc0 + ct_pass_c(ct, q) + g.c_lw;
+                const uint32_t idx = (ct_pass_h(ct, q) * ct.ci + g.c0 + crel) * ct.co + g.o0 + 4 * g.o4;
+                if (q == 0 || ct_pass_new(ct, q)) ctx = O::ctx_of(p, sc[q]);      // block-uniform condition
+                if (!LQ_ABLATE(1)) x[q] = O::elem4(p, ctx, idx, x[q], x[q], none);      // the outputs take the inputs' registers
+                if (!LQ_ABLATE(4)) store4<0>(p.out + idx, x[q]);
             }
         }
     }
-    if (p.out_perm) {
-        __syncthreads();
-        const uint32_t RL = g.tc_eff * ct.hw, E = g.to_eff * RL;
-        float* dst = p.out_perm + ((size_t)g.o0 * ct.ci + g.c0) * ct.hw;
+    if (p.out_perm && g.RLw && !LQ_ABLATE(2)) {
+        float* lw = lds + g.w * (kCtFwdStage * kCtStrideW);
+        float* dst = p.out_perm + ((size_t)g.o0 * ct.ci + g.c0 + g.wc0) * ct.hw;
         const uint32_t ostride = ct.ci * ct.hw;
-#pragma unroll 4
-        for (int i = 0; i < kCtIter; ++i) {
-            const uint32_t e = threadIdx.x + (uint32_t)i * kBlock;
-            if (e < E) {
-                uint32_t o_l, k;
-                ct_run(ct, g, e, o_l, k);
-                dst[o_l * ostride + k] = lds[o_l * kCtStride + k];
+#pragma unroll 1
+        for (uint32_t r = 0; r < (uint32_t)(kCtO / kCtFwdStage); ++r) {
+            if (r * kCtFwdStage >= g.to_eff) break;             // block-uniform
+            if ((g.o4 >> 1) == r) {                             // the lanes whose four output channels belong to this stage
+                float* wr = lw + ((4 * g.o4) & (kCtFwdStage - 1)) * kCtStrideW;
+#pragma unroll
+                for (int q = 0; q < kCtPass; ++q) {
+                    if (v[q]) {
+                        const uint32_t k = (ct_pass_c(ct, q) + g.c_lw) * ct.hw + ct_pass_h(ct, q);
+                        wr[k] = x[q].x;
+                        wr[k + kCtStrideW] = x[q].y;
+                        wr[k + 2 * kCtStrideW] = x[q].z;
+                        wr[k + 3 * kCtStrideW] = x[q].w;
+                    }
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t no = g.to_eff - r * kCtFwdStage < (uint32_t)kCtFwdStage ? g.to_eff - r * kCtFwdStage : (uint32_t)kCtFwdStage;
+            const uint32_t E = no * g.RLw;
+#pragma unroll
+            for (int i = 0; i < kCtFwdStage * kCtRunW / 64; ++i) {
+                const uint32_t e = g.lane + 64u * (uint32_t)i;
+                if (e < E) {
+                    const uint32_t o_l = (e * g.M) >> 20, k = e - o_l * g.RLw;
+                    dst[(r * kCtFwdStage + o_l) * ostride + k] = lw[o_l * kCtStrideW + k];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-//  K2 on a tile.  OIHW = true: dy arrives in OIHW order (p.dy_perm), goes through LDS and is written back in HWIO order
-//  to p.dp_out (dP == dy, custom_layers.py:118).  OIHW = false: dy is an HWIO tensor (p.dy), read like P.
+//  K2 on a tile: dy arrives in OIHW order (p.dy_perm), goes through the wave's LDS slice and is written back in HWIO order
+//  to p.dp_out (dP == dy, custom_layers.py:118).  (An HWIO gradient needs no tile: the plain entry points keep the generic
+//  traversals -- measured as fast on the ResNet-18-like set, a quarter faster on the ResNet-50-like one.)
 // ------------------------------------------------------------------------------------------
 template <int OP>
 __device__ __forceinline__ void ct_flush(const Params& p, const ConvTile& ct, const CtGeom& g, Acc& acc, uint32_t gq, bool mine) {
+    if (LQ_ABLATE(8)) {
+        if (acc.c == 12345.0) write_partial(p, 0, acc);
+        return;
+    }
     if (ct.kind == 0) {
         dpp_team_reduce<3>(acc);                      // the 8 lanes of a row (same c): every lane ends with the row total
         if (mine && g.o4 == 0) write_partial(p, (int64_t)gq * ct.nto + g.to, acc);
     } else {
         dpp_wave_reduce(acc);                         // lane 63 <- wave total
-        if ((threadIdx.x & 63) == 63)
-            write_partial(p, ((int64_t)gq * (ct.nto * ct.ntc) + g.tile) * kWavesPerBlock + (threadIdx.x >> 6), acc);
+        if (g.lane == 63) write_partial(p, ((int64_t)gq * (ct.nto * ct.ntc) + g.tile) * kWavesPerBlock + g.w, acc);
     }
 }
 
-template <bool OIHW>
+// The pass loop is ROLLED and software-pipelined with a ring of kCtAhead passes in flight.  Block timelines (tools/
+// block_timeline.py) of the first, unrolled version -- nine copies of the vote arithmetic, 10 000 instructions, 140 VGPRs,
+// three waves per SIMD -- showed every block alive for the whole launch; with two passes in flight a block that starts late
+// (the second round of a launch with more tiles than the chip holds) needed nine dependent memory round trips: 15 us alone
+// on an idle chip.
+constexpr int kCtAhead = 4;
+
 __device__ __forceinline__ void conv_tile_bwd(const Params& p, const ConvTile& ct, uint32_t b, float* lds) {
     using O = OpT<OP_BWD>;
     const CtGeom g = ct_geom(ct, b);
-    float4 x[kCtPass], d[kCtPass];
-    uint32_t idx[kCtPass], crel[kCtPass];
-    bool v[kCtPass];
+    float* lw = lds + g.w * (kCtO * kCtStrideW);
+    const uint32_t tconst = (g.c0 + g.wc0 + g.c_lw) * ct.co + g.o0 + 4 * g.o4;      // + pass_off[q] = HWIO index of the lane's float4
+    const uint32_t climit = g.tc_eff > g.wc0 + g.c_lw ? g.tc_eff - g.wc0 - g.c_lw : 0u;   // pass q is this lane's iff pass_c[q] < climit
+    const int np = (int)ct.npass;
+    auto valid = [&](int q) { return g.ov && ct_pass_c(ct, q) < climit; };
+    auto group = [&](int q) { return ct.kind == 0 ? g.c0 + g.wc0 + g.c_lw + ct_pass_c(ct, q) : ct_pass_g(ct, q); };
+    // ring of the next kCtAhead passes: P and the scale of the pass's group (a scale fetched inside the loop stalls the wave)
+    float4 x[kCtAhead];
+    float sc[kCtAhead];
+    // every load is unconditional (clamped to the tile's first float4 / scale 0): see conv_tile_fwd
+    const uint32_t idx_safe = g.c0 * ct.co + g.o0;
 #pragma unroll
-    for (int q = 0; q < kCtPass; ++q) {
-        crel[q] = ct.pass_c[q] + g.c_l;
-        v[q] = q < (int)ct.npass && crel[q] < g.tc_eff && g.ov;
-        idx[q] = ((uint32_t)ct.pass_h[q] * ct.ci + g.c0 + crel[q]) * ct.co + g.o0 + 4 * g.o4;
-        x[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        d[q] = x[q];
-        if (v[q]) {
-            x[q] = load4<0>(p.P + idx[q]);
-            if (!OIHW) d[q] = load4<0>(p.dy + idx[q]);
-        }
+    for (int a = 0; a < kCtAhead; ++a) {
+        const bool va = a < np && valid(a);
+        x[a] = load4<0>(p.P + (va ? tconst + ct.pass_off[a] : idx_safe));
+        sc[a] = p.s[va ? group(a) : 0u];
     }
-    if (OIHW) {
-        const uint32_t RL = g.tc_eff * ct.hw, E = g.to_eff * RL;
-        const float* src = p.dy_perm + ((size_t)g.o0 * ct.ci + g.c0) * ct.hw;
+    if (!LQ_ABLATE(2)) {
+        // the wave's slice of the OIHW gradient into LDS in run order: 36 independent 256-byte loads, all in flight at once
+        // (in four rounds of nine every wave paid four memory round trips before its first pass)
+        const uint32_t E = g.to_eff * g.RLw;
+        // (a wave without channels -- the last c-tile of a kernel with few input channels -- reads element 0 of the tensor)
+        const float* src = E ? p.dy_perm + ((size_t)g.o0 * ct.ci + g.c0 + g.wc0) * ct.hw : p.dy_perm;
         const uint32_t ostride = ct.ci * ct.hw;
-        // the run-order loads in four rounds of nine (36 further registers in flight would cost a wave of occupancy)
+        constexpr int NI = kCtO * kCtRunW / 64;      // 36
+        float t[NI];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float t[kCtIter / 4];
-            uint32_t a[kCtIter / 4];
-#pragma unroll
-            for (int i = 0; i < kCtIter / 4; ++i) {
-                const uint32_t e = threadIdx.x + (uint32_t)(r * (kCtIter / 4) + i) * kBlock;
-                uint32_t o_l = 0, k = 0;
-                t[i] = 0.f;
-                a[i] = 0xffffffffu;
-                if (e < E) {
-                    ct_run(ct, g, e, o_l, k);
-                    t[i] = src[o_l * ostride + k];
-                    a[i] = o_l * kCtStride + k;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < kCtIter / 4; ++i)
-                if (a[i] != 0xffffffffu) lds[a[i]] = t[i];
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t e = g.lane + 64u * (uint32_t)i;
+            const uint32_t ec = e < E ? e : 0u;                  // clamp: the loads stay unconditional (E > 0 whenever a lane is valid)
+            const uint32_t o_l = (ec * g.M) >> 20, k = ec - o_l * g.RLw;
+            t[i] = src[o_l * ostride + k];
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t e = g.lane + 64u * (uint32_t)i;
+            if (e < E) {
+                const uint32_t o_l = (e * g.M) >> 20, k = e - o_l * g.RLw;
+                lw[o_l * kCtStrideW + k] = t[i];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_sched_barrier(0);
     Acc acc = O::template init<Acc>();
-    Ctx ctx = O::ctx(p, 0);
-    uint32_t gprev = 0xffffffffu;
-    bool mine = false;                                // this thread accumulated something for gprev
+    Ctx ctx = O::ctx_of(p, 1.0f);
+    uint32_t gcur = 0;
+    bool mine = false;                                // this lane accumulated something for the current group
+    const float* lr = lw + (4 * g.o4) * kCtStrideW + g.c_lw * ct.hw;
+    // slot a of the ring serves passes a, a + kCtAhead, ...: it is refilled right after its pass was computed, so a pass's
+    // loads are issued kCtAhead - 1 passes before their use.  (A ring that SHIFTS its registers every pass makes the compiler
+    // wait for the newest load at the copy: no pipelining at all -- the first version of this loop.)
+#pragma unroll 1
+    for (int q0 = 0; q0 < np; q0 += kCtAhead) {
 #pragma unroll
-    for (int q = 0; q < kCtPass; ++q) {
-        if (q < (int)ct.npass) {                      // block-uniform
-            if (q > 0 && ct.pass_new[q]) {            // block-uniform: the group changes here for every thread
-                ct_flush<OP_BWD>(p, ct, g, acc, gprev, mine);
-                acc = O::template init<Acc>();
-                mine = false;
-                gprev = 0xffffffffu;
-            }
-            if (v[q]) {
-                const uint32_t gq = ct.kind == 0 ? g.c0 + crel[q] : (uint32_t)ct.pass_g[q];
-                if (gq != gprev) {
-                    ctx = O::ctx(p, gq);
-                    gprev = gq;
+        for (int a = 0; a < kCtAhead; ++a) {
+            const int q = q0 + a;
+            if (q < np) {                                 // block-uniform
+                if (q == 0 || ct_pass_new(ct, q)) {           // block-uniform: a new group (kind 1) / a new channel block (kind 0)
+                    if (q > 0) {
+                        ct_flush<OP_BWD>(p, ct, g, acc, gcur, mine);
+                        acc = O::template init<Acc>();
+                        mine = false;
+                    }
+                    gcur = group(q);
+                    // kind 1: the group is block-uniform, but an idle lane carries no scale: it takes a valid lane's
+                    float sq = sc[a];
+                    if (ct.kind == 1) sq = __shfl(sc[a], __builtin_ctzll(__builtin_amdgcn_ballot_w64(valid(q)) | (1ull << 63)), 64);
+                    ctx = O::ctx_of(p, sq);
                 }
-                mine = true;
-                if (OIHW) {
-                    const float* r = lds + (4 * g.o4) * kCtStride + crel[q] * ct.hw + ct.pass_h[q];
-                    d[q] = make_float4(r[0], r[kCtStride], r[2 * kCtStride], r[3 * kCtStride]);
-                    store4<0>(p.dp_out + idx[q], d[q]);
+                if (valid(q)) {
+                    const uint32_t idx = tconst + ct.pass_off[q];
+                    mine = true;
+                    const float* r = lr + ct_pass_k(ct, q);
+                    float4 d = x[a];
+                    if (!LQ_ABLATE(2)) d = make_float4(r[0], r[kCtStrideW], r[2 * kCtStrideW], r[3 * kCtStrideW]);
+                    if (!LQ_ABLATE(4)) store4<0>(p.dp_out + idx, d);
+                    if (!LQ_ABLATE(1)) O::elem4(p, ctx, idx, x[a], d, acc);
+                    else acc.c += (double)(x[a].x + d.x);
                 }
-                O::elem4(p, ctx, idx[q], x[q], d[q], acc);
-            } else if (ct.kind == 1) {
-                gprev = ct.pass_g[q];                 // idle lanes still take part in the wave reduction of this group
+                if (q + kCtAhead < np) {                  // block-uniform
+                    const bool vn = valid(q + kCtAhead);
+                    x[a] = load4<0>(p.P + (vn ? tconst + ct.pass_off[q + kCtAhead] : idx_safe));
+                    sc[a] = p.s[vn ? group(q + kCtAhead) : 0u];
+                }
+                __builtin_amdgcn_sched_barrier(0);        // the refill is issued here, not sunk towards its use
             }
         }
     }
-    ct_flush<OP_BWD>(p, ct, g, acc, gprev, mine);
+    ct_flush<OP_BWD>(p, ct, g, acc, gcur, mine);
 }
 
 // single-tensor launches (lq_fq_forward_oihw / lq_fq_scale_grad_oihw)
 __global__ __launch_bounds__(kBlock) void k_conv_tile_fwd(Params p, ConvTile ct) {
-    __shared__ float lds[kCtLdsWords];
+    __shared__ float lds[kCtLdsWordsFwd];
     conv_tile_fwd(p, ct, blockIdx.x, lds);
 }
-template <bool OIHW>
 __global__ __launch_bounds__(kBlock) void k_conv_tile_bwd(Params p, ConvTile ct) {
-    __shared__ float lds[OIHW ? kCtLdsWords : 1];
-    conv_tile_bwd<OIHW>(p, ct, blockIdx.x, lds);
+    __shared__ float lds[kCtLdsWordsBwd];
+    conv_tile_bwd(p, ct, blockIdx.x, lds);
 }
 
 }  // namespace lq

@@ -904,6 +904,19 @@ extern "C" {
 
 int lq_version(void) { return LQ_ABI_VERSION; }
 
+#ifdef LQ_DEV_KNOBS
+int lq_dev_set_ablate(int mask) {      // development builds only (see lq_conv_tile.hpp)
+    return hipMemcpyToSymbol(HIP_SYMBOL(lq::g_ablate), &mask, sizeof(int)) == hipSuccess ? LQ_OK : LQ_EHIP;
+}
+#endif
+
+#ifdef LQ_DEV_KNOBS
+int lq_dev_set_trace(void* buf) {      // development builds only: block timeline of the batch traversals (lq_conv_tile.hpp)
+    unsigned long long* b = (unsigned long long*)buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(lq::g_trace), &b, sizeof(b)) == hipSuccess ? LQ_OK : LQ_EHIP;
+}
+#endif
+
 int lq_profile_events(void* start, void* stop) {
     g_prof_start = (hipEvent_t)start;
     g_prof_stop = (hipEvent_t)stop;
@@ -1026,7 +1039,7 @@ int lq_fq_scale_grad_oihw(const float* P, const float* s, const float* dy_oihw, 
             return fail(LQ_EWORKSPACE, "lq_fq_scale_grad_oihw: workspace too small: %zu < %zu bytes (size it with lq_conv_workspace_bytes)",
                         ws_bytes, ws_bytes_for(tp));
         if ((rc = bind_ws(p, tp, ws, ws_bytes))) return rc;
-        hipLaunchKernelGGL(k_conv_tile_bwd<true>, dim3(ct.ntc * ct.nto), dim3(kBlock), 0, (hipStream_t)stream, p, ct);
+        hipLaunchKernelGGL(k_conv_tile_bwd, dim3(ct.ntc * ct.nto), dim3(kBlock), 0, (hipStream_t)stream, p, ct);
         if ((rc = check_hip("conv tile backward launch"))) return rc;
         FinGeom f = group_geom(tp, outer, G, inner);
         f.o0 = ds;
@@ -1283,6 +1296,7 @@ struct lq_task_table {                    // one device-resident task table
     std::vector<int> index;               // table position -> descriptor index (tasks are ordered by work per block)
     lq::Task* d = nullptr;
     uint32_t* prefix_d = nullptr;         // [n] first block of every task, then [n] first group
+    uint16_t* block_task_d = nullptr;     // [blocks] task of every traversal block
     uint32_t blocks = 0, groups = 0;
     bool has_tile = false;                // some task runs the conv tile (needs the tile kernel's LDS)
     int64_t ws_words = 0;
@@ -1290,7 +1304,8 @@ struct lq_task_table {                    // one device-resident task table
 
 struct lq_batch {
     int n = 0;
-    lq_task_table fwd, bwd, pen;          // pen: every tensor, with workspace slices and mb/ties buffers (penalty passes)
+    lq_task_table fwd, bwd, bwd_o, pen;   // bwd: HWIO gradients (generic traversals); bwd_o: OIHW gradients of the conv kernels (tiles);
+                                          // pen: every tensor, with workspace slices and mb/ties buffers (penalty passes)
     std::vector<lq::AdamTask> adam_h;
     float* mb_d = nullptr;
     uint32_t* ties_d = nullptr;
@@ -1335,9 +1350,6 @@ static bool make_conv_tile(ConvTile& ct, int64_t hw, int64_t ci, int64_t co, int
     ct.npass = (uint32_t)(m * hw);
     ct.kind = (uint32_t)kind;
     ct.fnto = make_fastdiv(ct.nto);
-    ct.frun = make_fastdiv((uint32_t)(32 * m * hw));
-    const int64_t tc_last = ci - (int64_t)(ct.ntc - 1) * 32 * m;
-    ct.frun_edge = make_fastdiv((uint32_t)(tc_last * hw));
     // pass order: kind 0 by channel block, kind 1 group by group (one accumulator flush per group)
     struct PassKey { int g, j, h; };
     std::vector<PassKey> ps;
@@ -1345,10 +1357,9 @@ static bool make_conv_tile(ConvTile& ct, int64_t hw, int64_t ci, int64_t co, int
         for (int64_t h = 0; h < hw; ++h) ps.push_back({kind == 0 ? (int)j : (int)((h / A) % G), (int)j, (int)h});
     std::stable_sort(ps.begin(), ps.end(), [](const PassKey& a, const PassKey& b) { return a.g < b.g; });
     for (size_t q = 0; q < ps.size(); ++q) {
-        ct.pass_c[q] = (uint16_t)(32 * ps[q].j);
-        ct.pass_h[q] = (uint8_t)ps[q].h;
-        ct.pass_g[q] = (uint8_t)(kind == 0 ? 0 : ps[q].g);
-        ct.pass_new[q] = (uint8_t)(q > 0 && ps[q].g != ps[q - 1].g);
+        const uint32_t is_new = (q > 0 && ps[q].g != ps[q - 1].g) ? 1u : 0u;
+        ct.pass_info[q] = (uint32_t)(8 * ps[q].j) | ((uint32_t)ps[q].h << 8) | ((uint32_t)(kind == 0 ? 0 : ps[q].g) << 16) | (is_new << 24);
+        ct.pass_off[q] = (uint32_t)(((int64_t)ps[q].h * ci + 8 * ps[q].j) * co);
     }
     return true;
 }
@@ -1468,8 +1479,15 @@ static int finish_table(lq_task_table& tb, bool bwd) {
     tb.blocks = (uint32_t)bp;
     tb.groups = (uint32_t)gp;
     tb.ws_words = words;
+    std::vector<uint16_t> bt((size_t)bp);
+    for (size_t k = 0; k < n; ++k) {
+        const uint64_t end = k + 1 < n ? prefix[k + 1] : bp;
+        for (uint64_t b = prefix[k]; b < end; ++b) bt[b] = (uint16_t)k;
+    }
     hipError_t e = hipMalloc(&tb.prefix_d, 2 * n * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(tb.prefix_d, prefix.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&tb.block_task_d, bt.size() * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpy(tb.block_task_d, bt.data(), bt.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&tb.d, n * sizeof(Task));
     if (e != hipSuccess) return fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
     return LQ_OK;
@@ -1485,6 +1503,8 @@ static int upload_table(lq_task_table& tb) {
 static void free_table(lq_task_table& tb) {
     if (tb.d) (void)hipFree(tb.d);
     if (tb.prefix_d) (void)hipFree(tb.prefix_d);
+    if (tb.block_task_d) (void)hipFree(tb.block_task_d);
+    tb.block_task_d = nullptr;
     tb.d = nullptr;
     tb.prefix_d = nullptr;
 }
@@ -1528,9 +1548,12 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
                 break;
             }
             Task tb;
-            if ((rc = fill_task(tb, d, true, true, b->bwd))) break;
+            if ((rc = fill_task(tb, d, true, false, b->bwd))) break;
             b->bwd.h.push_back(tb);
             b->bwd.index.push_back(i);
+            if ((rc = fill_task(tb, d, true, true, b->bwd_o))) break;
+            b->bwd_o.h.push_back(tb);
+            b->bwd_o.index.push_back(i);
         }
         if (d.m && d.v) {
             AdamTask a;
@@ -1550,6 +1573,7 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
     }
     if (!rc) rc = finish_table(b->fwd, false);
     if (!rc) rc = finish_table(b->bwd, true);
+    if (!rc) rc = finish_table(b->bwd_o, true);
     if (!rc) rc = finish_table(b->pen, true);
     if (!rc && !b->pen.h.empty()) {
         hipError_t e = hipMalloc(&b->mb_d, (size_t)b->pen.groups * sizeof(float));
@@ -1562,6 +1586,7 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
     }
     if (!rc) rc = upload_table(b->fwd);
     if (!rc) rc = upload_table(b->bwd);
+    if (!rc) rc = upload_table(b->bwd_o);
     if (!rc) rc = upload_table(b->pen);
     if (!rc && !b->adam_h.empty()) {
         hipError_t e = hipMalloc(&b->adam_d, b->adam_h.size() * sizeof(AdamTask));
@@ -1575,7 +1600,8 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
         memcpy(g_err, keep, sizeof(keep));
         return rc;
     }
-    const int64_t words = b->bwd.ws_words > b->pen.ws_words ? b->bwd.ws_words : b->pen.ws_words;
+    int64_t words = b->bwd.ws_words > b->pen.ws_words ? b->bwd.ws_words : b->pen.ws_words;
+    if (b->bwd_o.ws_words > words) words = b->bwd_o.ws_words;
     b->ws_bytes = (size_t)words * 4 + 256;
     *out = b;
     return LQ_OK;
@@ -1585,6 +1611,7 @@ int lq_batch_destroy(lq_batch* b) {
     if (!b) return LQ_OK;
     free_table(b->fwd);
     free_table(b->bwd);
+    free_table(b->bwd_o);
     free_table(b->pen);
     if (b->adam_d) (void)hipFree(b->adam_d);
     if (b->mb_d) (void)hipFree(b->mb_d);
@@ -1602,10 +1629,10 @@ int lq_batch_forward(const lq_batch* b, void* stream) {
     const lq_task_table& tb = b->fwd;
     const int nt = (int)tb.h.size();
     if (b->has_perm)
-        hipLaunchKernelGGL((k_batch_traverse<OP_FWD_PERM>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.prefix_d, nt,
+        hipLaunchKernelGGL((k_batch_traverse<OP_FWD_PERM>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.block_task_d, nt,
                            (uint32_t*)nullptr, pk, 0, cf);
     else
-        hipLaunchKernelGGL((k_batch_traverse<OP_FWD>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.prefix_d, nt,
+        hipLaunchKernelGGL((k_batch_traverse<OP_FWD>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.block_task_d, nt,
                            (uint32_t*)nullptr, pk, 0, cf);
     return check_hip("batch forward launch");
 }
@@ -1632,7 +1659,7 @@ int lq_batch_scale_grad_oihw(const lq_batch* b, const float* const* dy, void* ws
 
 static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream, bool oihw) {
     if (!b) return fail(LQ_EINVAL, "lq_batch_scale_grad: NULL batch");
-    const lq_task_table& tb = b->bwd;
+    const lq_task_table& tb = oihw ? b->bwd_o : b->bwd;
     if (tb.h.empty()) return LQ_OK;
     if (!ws) return fail(LQ_EWORKSPACE, "lq_batch_scale_grad: workspace is NULL (need %zu bytes)", b->ws_bytes);
     if (!aligned(ws, 16)) return fail(LQ_EALIGN, "lq_batch_scale_grad: workspace must be 16-byte aligned");
@@ -1653,12 +1680,11 @@ static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws,
     if (!all_aligned) return fail(LQ_EALIGN, "lq_batch_scale_grad: a 16-byte aligned tensor got a dy that is not 16-byte aligned");
     CoefPack cf;
     const int nt = (int)tb.h.size();
-    // the kernel with the conv-tile LDS whenever a tile task is in the table (its generic bodies compute what OP_BWD's do)
-    if (oihw || tb.has_tile)
-        hipLaunchKernelGGL((k_batch_traverse<OP_BWD_PERM>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.prefix_d, nt,
+    if (oihw)
+        hipLaunchKernelGGL((k_batch_traverse<OP_BWD_PERM>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.block_task_d, nt,
                            (uint32_t*)ws, pk, oihw ? 3 : 1, cf);
     else
-        hipLaunchKernelGGL((k_batch_traverse<OP_BWD>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.prefix_d, nt,
+        hipLaunchKernelGGL((k_batch_traverse<OP_BWD>), dim3(tb.blocks), dim3(kBlock), 0, (hipStream_t)stream, tb.d, tb.block_task_d, nt,
                            (uint32_t*)ws, pk, 1, cf);
     int rc = check_hip("batch scale-grad launch");
     if (rc) return rc;
@@ -1707,12 +1733,12 @@ int lq_batch_penalty_grads(const lq_batch* b, int kind, const float* coeff, floa
     if (kind == LQ_PENALTY_MAXBIN) {
         PtrPack none;
         memset(&none, 0, sizeof(none));
-        hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_FWD>), dim3(tb.blocks), dim3(kBlock), 0, st, tb.d, tb.prefix_d, nt, (uint32_t*)ws, none, 0, cf);
+        hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_FWD>), dim3(tb.blocks), dim3(kBlock), 0, st, tb.d, tb.block_task_d, nt, (uint32_t*)ws, none, 0, cf);
         hipLaunchKernelGGL((k_batch_finalize<OP_MAXBIN_FWD>), dim3(tb.groups), dim3(64), 0, st, tb.d, gpre, nt, (uint32_t*)ws, 0);
-        hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_BWD>), dim3(tb.blocks), dim3(kBlock), 0, st, tb.d, tb.prefix_d, nt, (uint32_t*)ws, pk, 2, cf);
+        hipLaunchKernelGGL((k_batch_traverse<OP_MAXBIN_BWD>), dim3(tb.blocks), dim3(kBlock), 0, st, tb.d, tb.block_task_d, nt, (uint32_t*)ws, pk, 2, cf);
         hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(tb.groups, kBlock)), dim3(kBlock), 0, st, tb.d, gpre, nt, tb.groups, 0, cf, accum);
     } else if (kind == LQ_PENALTY_DIFFERENCE) {
-        hipLaunchKernelGGL((k_batch_traverse<OP_DIFF_BWD>), dim3(tb.blocks), dim3(kBlock), 0, st, tb.d, tb.prefix_d, nt, (uint32_t*)ws, pk, 2, cf);
+        hipLaunchKernelGGL((k_batch_traverse<OP_DIFF_BWD>), dim3(tb.blocks), dim3(kBlock), 0, st, tb.d, tb.block_task_d, nt, (uint32_t*)ws, pk, 2, cf);
         hipLaunchKernelGGL((k_batch_finalize<OP_DIFF_BWD>), dim3(tb.groups), dim3(64), 0, st, tb.d, gpre, nt, (uint32_t*)ws, accum);
     } else {
         hipLaunchKernelGGL(k_batch_penalty_ds, dim3((unsigned)ceil_div(tb.groups, kBlock)), dim3(kBlock), 0, st, tb.d, gpre, nt, tb.groups, 2, cf, accum);

@@ -34,19 +34,22 @@ struct OpBase {
         x.b += y.b;
         x.c += y.c;
     }
-    __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) {
+    __device__ static __forceinline__ Ctx ctx_of(const Params& p, float s) {      // context of a scale that is already in a register
         Ctx c;
-        c.s = p.s[g];
+        c.s = s;
         div_ctx(c);
         c.k0 = 0.f;
         c.k1 = 0.f;
         vote_ctx(c, p.lam);
         return c;
     }
+    __device__ static __forceinline__ Ctx ctx(const Params& p, int64_t g) { return ctx_of(p, p.s[g]); }
 };
 
-// PERM = true: the variant that can also emit the OIHW companion of an HWIO conv kernel (used by the multi-tensor batch and
-// the *_oihw entry points only: the streaming kernels of the BENCH path keep the lean instantiation)
+// PERM = true: the variant that can also emit the OIHW companion of an HWIO conv kernel ELEMENT BY ELEMENT -- the fallback
+// for the conv kernels lq_conv_tile.hpp does not take (more than 9 taps: a 7x7 stem; co % 4 != 0; exotic descriptors).  The
+// companion costs two integer divisions and a 4-byte scattered store per element, so these instantiations provide the
+// scalar element path only (kVec4 = false: the traversals still load float4, the op walks its elements).
 template <bool PERM>
 struct FwdOp : OpBase {
     static constexpr bool kStore = true;
@@ -57,32 +60,29 @@ struct FwdOp : OpBase {
             store_q(p.q, p.q_dtype, i + 2, q.z);
             store_q(p.q, p.q_dtype, i + 3, q.w);
         }
-        if constexpr (PERM) {
-            if (p.out_perm) {                   // the OIHW companion of an HWIO conv kernel (weight-sized tensors)
-                p.out_perm[perm_index(p, i + 0)] = o.x;
-                p.out_perm[perm_index(p, i + 1)] = o.y;
-                p.out_perm[perm_index(p, i + 2)] = o.z;
-                p.out_perm[perm_index(p, i + 3)] = o.w;
-            }
-        }
+    }
+    __device__ static __noinline__ void scatter1(float* __restrict__ out_perm, uint32_t hw, uint32_t ci, uint32_t co, uint32_t i, float o) {
+        const uint32_t t = i / co, oc = i - t * co;
+        const uint32_t h = t / ci, c = t - h * ci;
+        out_perm[(oc * ci + c) * hw + h] = o;
     }
     __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float, Acc&) {
         float q, o;
         fq_core(x, c, q, o);
         if (p.q) store_q(p.q, p.q_dtype, i, q);
         if constexpr (PERM) {
-            if (p.out_perm) p.out_perm[perm_index(p, i)] = o;
+            if (p.out_perm) scatter1(p.out_perm, p.perm_hw, p.perm_ci, p.perm_co, (uint32_t)i, o);
         }
         return o;
     }
-    static constexpr bool kVec4 = true;
+    static constexpr bool kVec4 = !PERM;
     __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t i, const float4& x, const float4&, Acc&) {
         float4 q, o;
         fq_core4(x, c, q, o);
         side4(p, i, q, o);
         return o;
     }
-    static constexpr bool kVec4c = true;
+    static constexpr bool kVec4c = !PERM;
     __device__ static __forceinline__ float4 elem4c(const Params& p, const Ctx* c, int64_t i, const float4& x, const float4&, Acc*) {
         float4 q, o;
         fq_core4c(x, c, q, o);
@@ -111,44 +111,36 @@ struct BwdOp : OpBase {
     static constexpr bool kReduce = true;
     // upstream gradient of an HWIO conv kernel that arrives in OIHW order (MIOpen's weight gradient): gathered here, and
     // handed back in HWIO order as dP (dP == dy, custom_layers.py:118) -- weight-sized tensors, L2-resident
-    __device__ static __forceinline__ float gather1(const Params& p, int64_t i) {
-        const float d = p.dy_perm[perm_index(p, i)];
-        p.dp_out[i] = d;
-        return d;
-    }
-    __device__ static __forceinline__ float4 gather4(const Params& p, int64_t i) {
-        float4 d;
-        d.x = p.dy_perm[perm_index(p, i + 0)];
-        d.y = p.dy_perm[perm_index(p, i + 1)];
-        d.z = p.dy_perm[perm_index(p, i + 2)];
-        d.w = p.dy_perm[perm_index(p, i + 3)];
-        p.dp_out[i + 0] = d.x;
-        p.dp_out[i + 1] = d.y;
-        p.dp_out[i + 2] = d.z;
-        p.dp_out[i + 3] = d.w;
+    // out of line: the fallback serves a 7x7 stem or an odd head, its divisions need not sit in every traversal's registers
+    __device__ static __noinline__ float gather1(const float* __restrict__ dy_perm, float* __restrict__ dp_out, uint32_t hw, uint32_t ci,
+                                                 uint32_t co, uint32_t i) {
+        const uint32_t t = i / co, o = i - t * co;
+        const uint32_t h = t / ci, c = t - h * ci;
+        const float d = dy_perm[(o * ci + c) * hw + h];
+        dp_out[i] = d;
         return d;
     }
     __device__ static __forceinline__ float elem(const Params& p, const Ctx& c, int64_t i, float x, float dy, Acc& acc) {
         float q, o;
         fq_core(x, c, q, o);
         if constexpr (PERM) {
-            if (p.dy_perm) dy = gather1(p, i);
+            if (p.dy_perm) dy = gather1(p.dy_perm, p.dp_out, p.perm_hw, p.perm_ci, p.perm_co, (uint32_t)i);
         }
         nq_accumulate(q, o, dy, p.lam, p.tmode, acc);
         return 0.f;
     }
-    static constexpr bool kVec4 = true;
-    __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t i, const float4& x, const float4& dy, Acc& acc) {
+    static constexpr bool kVec4 = !PERM;       // PERM: scalar element path only (see FwdOp)
+    __device__ static __forceinline__ float4 elem4(const Params& p, const Ctx& c, int64_t, const float4& x, const float4& dy, Acc& acc) {
         float4 q, o;
         fq_core4(x, c, q, o);
-        nq_accumulate4(q, o, (PERM && p.dy_perm) ? gather4(p, i) : dy, c, p.lam, p.tmode, acc);
+        nq_accumulate4(q, o, dy, c, p.lam, p.tmode, acc);
         return o;
     }
-    static constexpr bool kVec4c = true;
-    __device__ static __forceinline__ float4 elem4c(const Params& p, const Ctx* c, int64_t i, const float4& x, const float4& dy, Acc* acc) {
+    static constexpr bool kVec4c = !PERM;
+    __device__ static __forceinline__ float4 elem4c(const Params& p, const Ctx* c, int64_t, const float4& x, const float4& dy, Acc* acc) {
         float4 q, o;
         fq_core4c(x, c, q, o);
-        nq_accumulate4c(q, o, (PERM && p.dy_perm) ? gather4(p, i) : dy, c, p.lam, p.tmode, acc);
+        nq_accumulate4c(q, o, dy, c, p.lam, p.tmode, acc);
         return o;
     }
 };

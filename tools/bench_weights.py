@@ -37,9 +37,16 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--only", default=None, help="config:orientation, e.g. mnist:columnwise")
     ap.add_argument("--abi-only", action="store_true", help="time only the raw batch ABI (profiling runs)")
+    ap.add_argument("--ablate", type=int, default=0, help="development library only (LQ_HIP_LIB=.../liblq_hip_dev.so): lq_dev_set_ablate mask")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     rows = []
+    if args.ablate:
+        import ctypes as _ct
+        _lib = lq._hip.load()
+        _lib.lq_dev_set_ablate.restype = _ct.c_int
+        _lib.lq_dev_set_ablate.argtypes = [_ct.c_int]
+        assert _lib.lq_dev_set_ablate(args.ablate) == 0
     for config, lam in (("mnist", 1e-10), ("cifar", 1e-11), ("imagenette", 1e-11), ("resnet50", 1e-11)):
         for orient in (("rowwise", "columnwise", "scalar") if config == "mnist" else ("rowwise", "columnwise", "channelwise", "scalar")):
             if args.only and args.only != f"{config}:{orient}":
