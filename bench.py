@@ -63,14 +63,19 @@ def parse():
     ap.add_argument("--sets", type=int, default=4, help="rotating buffer sets (>= 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-every", type=int, default=0, help="(ignored: the roofline leg now runs after the timed loop)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (one graph per buffer set)")
+    ap.add_argument("--graph", action="store_true", help="replay the steps from captured hipGraphs of --graph-steps steps each "
+                    "(with torch.distributed: the scale-gradient all-reduce sits on a forked branch of the graph)")
+    ap.add_argument("--graph-steps", type=int, default=8, help="steps per captured graph (a multiple of the buffer sets keeps the rotation)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the informational extra measurements (N=1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl = RCCL over xGMI (default). "
                     "'gloo' + --share-gpu rehearses the N>1 code path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--exchange", choices=["async", "sync"], default="sync",
-                    help="scale-gradient all-reduce: sync (runs on the compute stream: ~10 us/step measured) or async (RCCL side stream + events: ~27 us/step)")
+    ap.add_argument("--exchange", choices=["auto", "graph", "async", "sync"], default="auto",
+                    help="scale-gradient all-reduce: graph (captured on a forked branch of the step graph: cross-stream edges cost no "
+                         "events; the default on RCCL, implies --graph), sync (eager, on the compute stream: ~10 us/step measured on a "
+                         "one-rank communicator; the fallback when the capture fails, and the default on other backends) or async "
+                         "(eager, RCCL side stream + events: ~27 us/step)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (exercises the RCCL path)")
     return ap.parse_args()
 
@@ -185,7 +190,7 @@ def main():
     def exchange(i):
         """learned-scale gradient exchange (mode A): mean over ranks, asynchronous."""
         b = i & 1
-        if args.exchange == "sync":
+        if exchange_form != "async":
             if avg_op is not None:
                 dist.all_reduce(dss[b], op=avg_op)
             else:
@@ -233,44 +238,90 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    graphs = None
-    if args.graph:
-        # one captured graph per buffer set: the launch-bound inner loop becomes one hipGraphLaunch per step
-        graphs = []
-        side = torch.cuda.Stream(dev)
-        with torch.cuda.stream(side):
-            for k in range(nsets):
-                gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph, stream=side):
-                    cs = torch.cuda.current_stream(dev).cuda_stream or None
-                    if args.variant == "split":
-                        rc = fwd(px[k], ps, pout[k], None, 0, outer, G, inner, cs)
-                        rc |= bwd(px[k], ps, pdy[k], lam, pds, None, pws, ws_bytes, outer, G, inner, cs)
-                    else:
-                        rc = fused(px[k], ps, pdy[k], lam, pout[k], pds, pws, ws_bytes, outer, G, inner, cs)
-                    if rc:
-                        _hip.check(rc, "graph capture")
-                graphs.append(gph)
-        torch.cuda.synchronize(dev)
+    # ---- the graphed form.  A captured graph holds S consecutive steps; with torch.distributed the all-reduce of step j's
+    # scale gradient sits on a FORKED branch (one side stream per gradient buffer) that is joined right before the launch
+    # that rewrites that buffer two steps later -- inside a graph the cross-stream edges are graph dependencies, they cost
+    # no event traffic (the eager async form pays ~27 us per step for them), and the collective of step j runs under the
+    # kernels of steps j+1 and j+2 (the exchange overlaps the backward of the other layers; custom_layers.py:116-118).
+    # Only the collectives of a graph's last two steps are exposed: one small all-reduce per S steps.
+    exchange_form = args.exchange
+    if exchange_form == "auto":
+        exchange_form = "graph" if (use_dist and args.backend == "nccl") else "sync"
+    if not use_dist:
+        exchange_form = None
+    want_graph = args.graph or exchange_form == "graph"
+    if exchange_form == "graph" and args.backend != "nccl":
+        raise SystemExit("--exchange graph needs --backend nccl (only RCCL collectives can be stream-captured)")
+    graph_note = None
 
-        def step(i, ev=None):  # noqa: F811
-            if use_dist and pending[0] is not None:
-                pending[0].wait()
-                pending[0] = None
-            if ev:
-                ev[0].record(stream)
-            graphs[i % nsets].replay()          # the captured launches write dss[0]
-            if ev:
-                ev[2].record(stream)
+    def capture(S):
+        gph = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream(dev)
+        sides = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        # a process group's watchdog THREAD polls events while this thread captures: "thread_local" keeps that legal
+        with torch.cuda.graph(gph, stream=cap, capture_error_mode="thread_local" if use_dist else "global"):
+            main = torch.cuda.current_stream(dev)
+            cs = main.cuda_stream or None
+            for j in range(S):
+                k, b = j % nsets, j & 1
+                if args.variant == "split":
+                    rc = fwd(px[k], ps, pout[k], None, 0, outer, G, inner, cs)
+                    if use_dist and j >= 2:
+                        main.wait_stream(sides[b])         # join: the all-reduce of step j-2 is done with dss[b]
+                    rc |= bwd(px[k], ps, pdy[k], lam, pdss[b], None, pws, ws_bytes, outer, G, inner, cs)
+                else:
+                    if use_dist and j >= 2:
+                        main.wait_stream(sides[b])
+                    rc = fused(px[k], ps, pdy[k], lam, pout[k], pdss[b], pws, ws_bytes, outer, G, inner, cs)
+                if rc:
+                    _hip.check(rc, "graph capture")
+                if use_dist:
+                    sides[b].wait_stream(main)             # fork
+                    with torch.cuda.stream(sides[b]):
+                        if avg_op is not None:
+                            dist.all_reduce(dss[b], op=avg_op)
+                        else:
+                            dss[b].div_(world)
+                            dist.all_reduce(dss[b], op=dist.ReduceOp.SUM)
             if use_dist:
-                exchange(0)
+                main.wait_stream(sides[0])
+                main.wait_stream(sides[1])
+        return gph
 
-    for i in range(args.warmup):
-        step(i)
+    graphs = None
+    if want_graph:
+        S = max(1, args.graph_steps)
+        try:
+            torch.cuda.synchronize(dev)
+            graphs = {S: capture(S)}
+            for r in {args.warmup % S, args.steps % S} - {0}:
+                graphs[r] = capture(r)                     # the remainder of a loop whose length is not a multiple of S
+            torch.cuda.synchronize(dev)
+        except Exception as e:                             # a stack that cannot capture the collective: the eager form runs
+            if args.graph or args.exchange == "graph":
+                raise
+            graphs = None
+            exchange_form = "sync"
+            graph_note = f"graph capture failed ({e!r}"[:200] + "): eager sync exchange"
+    if exchange_form == "graph" and graphs is None:
+        exchange_form = "sync"
+
+    def run_steps(n):
+        """n steps of the path: eager launches, or replays of the S-step graph plus one remainder graph."""
+        if graphs is None:
+            for i in range(n):
+                step(i)
+            return
+        S = max(graphs)
+        for _ in range(n // S):
+            graphs[S].replay()
+        if n % S:
+            graphs[n % S].replay()
+
+    run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -335,7 +386,7 @@ def main():
 
     # ---- informational extras (not part of `value`): other variants of the same step, 100 steps each, no events
     extras = {}
-    if world == 1 and not args.no_extras and not args.graph:
+    if world == 1 and not args.no_extras and graphs is None:
         def timed(fn, n=100):
             for i in range(10):
                 fn(i)
@@ -439,6 +490,11 @@ def main():
                                    f"{args.scale} scales, lambda={lam:g}",
                        "per_gpu_batch": BATCH, "global_batch": BATCH * world, "parallelism": f"dp{world}",
                        "buffer_sets": nsets, "algorithmic_bytes_per_step": step_bytes,
+                       "launch": (f"hipGraph of {max(graphs)} steps" if graphs is not None else "eager"),
+                       "exchange": ({"graph": "RCCL all-reduce of ds captured on a forked branch of the step graph",
+                                     "sync": "eager all-reduce of ds on the compute stream",
+                                     "async": "eager all-reduce of ds on RCCL's stream"}.get(exchange_form) if use_dist else None),
+                       **({"note": graph_note} if graph_note else {}),
                        "step_GBs": step_bytes / (elapsed / args.steps) / 1e9},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
@@ -448,7 +504,7 @@ def main():
                          "stream_ceiling_GBs": {"read1_write1": 6579, "read2": 6808, "read2_write1": 6507,
                                                 "source": "profiles/r01_membench.txt"}},
         }
-        if world == 1 and not args.no_extras and not args.graph:
+        if world == 1 and not args.no_extras and graphs is None:
             line["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(lam, args.cpu_seconds)

@@ -81,6 +81,13 @@ class Trainer:
             raise ValueError("a loss term needs mode 'cl' or 'nqcl'")
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         use_dp = self.world > 1 or (force_collectives and dist.is_initialized())
+        # Exact mode B reads the all-reduced P.grad as the global-batch dy (custom_layers.py:118): everything else that has a
+        # gradient with respect to P or s -- the loss term of "nqcl", weight regularisers -- is applied AFTER the scale
+        # gradients were recomputed (it is a function of the parameters only, identical on every rank: no exchange needed).
+        self._after_exchange = use_dp and ddp_mode == "B"
+        if self._after_exchange and mode == "nqcl" and not batched:
+            raise ValueError("mode 'nqcl' with ddp_mode 'B' needs batched=True: the loss term's gradients are injected after the "
+                             "exact scale gradients were recomputed, which the per-tensor autograd path cannot order")
         # graphed steps exchange after backward (hooks cannot launch collectives from inside a capture that is replayed
         # without them): overlap is a property of the eager step
         self.dp = DataParallel(self.model, mode=ddp_mode, bucket_mb=bucket_mb, overlap=overlap and not graph,
@@ -111,6 +118,10 @@ class Trainer:
         else:
             per_sample = sparse_categorical_crossentropy(y, p)
         total = per_sample.mean()
+        if self._after_exchange:                           # mode B: the regulariser GRADIENTS follow in _update_phase
+            for layer in self.regularized:
+                total = total + layer.regularization_loss().detach()
+            return total
         for layer in self.regularized:                     # Keras adds regulariser losses to the objective
             total = total + layer.regularization_loss()
         return total
@@ -127,16 +138,28 @@ class Trainer:
             self.batch.quantize_all()
         loss = self.loss(y, self.model(x))
         loss.backward()
-        if self.batch is not None and self.loss_obj is not None:
-            # batched custom-loss-terms mode: the task loss went through autograd, the penalty gradients are injected
-            # by the batch kernels (identical on every rank, so adding them before the all-reduce changes nothing);
-            # "nqcl": the penalty's ds is ADDED to the nested-quantization ds the batch has just written
-            self.batch.inject_penalty_grads(self.loss_kind, self.penalty_rate, accumulate_ds=(self.mode == "nqcl"))
+        if self.batch is not None and self.loss_obj is not None and not self._after_exchange:
+            self._inject_penalty()
         return loss
+
+    def _inject_penalty(self):
+        # batched custom-loss-terms mode: the task loss went through autograd, the penalty gradients are injected
+        # by the batch kernels (identical on every rank, so adding them before the all-reduce changes nothing);
+        # "nqcl": the penalty's ds is ADDED to the nested-quantization ds the batch has just written
+        self.batch.inject_penalty_grads(self.loss_kind, self.penalty_rate, accumulate_ds=(self.mode == "nqcl"))
 
     def _update_phase(self):
         if self.dp is not None:
-            self.dp.recompute_scale_grads()          # mode B only
+            self.dp.recompute_scale_grads()          # mode B only: ds from the pure task-loss P.grad
+        if self._after_exchange:
+            if self.batch is not None and self.loss_obj is not None:
+                self._inject_penalty()
+            if self.regularized:
+                with self.dp.no_sync():              # a second backward into the exchanged bucket, on purpose
+                    reg = self.regularized[0].regularization_loss()
+                    for layer in self.regularized[1:]:
+                        reg = reg + layer.regularization_loss()
+                    reg.backward()
         self.opt.step()
         self.scale_opt.step()
 

@@ -281,3 +281,28 @@ def test_batch_abi_validation_without_gpu():
     assert lib.lq_batch_workspace_bytes(None) == 0
     assert lib.lq_batch_destroy(None) == 0
     assert lib.lq_selftest_ratio_division(1, 0, 1, None, None) == -1
+
+
+def test_shipped_library_reads_no_environment(tmp_path):
+    """The development knobs (LQ_TUNE_*: traversal plan, partial layout, summation order) exist only in `make dev` builds
+    (-DLQ_DEV_KNOBS, tools/): the shipped library does not import getenv at all, and its plan is a pure function of the
+    descriptor -- lq_workspace_bytes is the same with every knob of the sources set."""
+    import subprocess
+    import sys
+    src_dir = os.path.join(os.path.dirname(_hip.LIB_PATH))
+    knobs = set()
+    for f in os.listdir(src_dir):
+        if f.endswith((".hip", ".hpp")):
+            knobs |= set(re.findall(r'"(LQ_TUNE_[A-Z0-9_]+)"', open(os.path.join(src_dir, f)).read()))
+    assert len(knobs) >= 15, knobs
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", _hip.LIB_PATH], text=True)
+    assert "getenv" not in undefined, "the shipped library must not read the environment"
+    probe = ("import ctypes, json; lib = ctypes.CDLL(%r); "
+             "lib.lq_workspace_bytes.restype = ctypes.c_size_t; lib.lq_workspace_bytes.argtypes = [ctypes.c_int64] * 3; "
+             "print(json.dumps([lib.lq_workspace_bytes(*d) for d in "
+             "[(256, 3, 50176), (1, 1, 38535168), (1, 784, 128), (784, 128, 1), (9, 64, 128), (32768, 1001, 1), (1, 65536, 512), "
+             "(1, 1048576, 32), (602112, 64, 1), (256, 2048, 49), (1, 8192, 4100), (12845056, 3, 1)]]))") % _hip.LIB_PATH
+    base = subprocess.check_output([sys.executable, "-c", probe], text=True, env={k: v for k, v in os.environ.items() if not k.startswith("LQ_TUNE_")})
+    for value in ("0", "1", "3", "128"):
+        env = dict(os.environ, **{k: value for k in knobs})
+        assert subprocess.check_output([sys.executable, "-c", probe], text=True, env=env) == base, f"LQ_TUNE_* = {value} changed the plan"

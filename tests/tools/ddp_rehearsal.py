@@ -27,11 +27,12 @@ from learned_quantization_amd.train import Trainer, synthetic_batch  # noqa: E40
 
 STEPS = 4
 ONLY_CAPTURED_COLLECTIVES = len(sys.argv) > 2 and sys.argv[2] == "collectives"
-x, y = synthetic_batch("mnist", 32, dev, torch.Generator(device=dev).manual_seed(0))
+X, Y = synthetic_batch("mnist", 32, dev, torch.Generator(device=dev).manual_seed(0))
 
 
-def run(graph=False, steps=STEPS, **kw):
-    tr = Trainer("mnist", "nq", 2e-4, "rowwise", None, device=dev, seed=42, graph=graph, **kw)
+def run(graph=False, steps=STEPS, setup=("mnist", "nq", 2e-4, "rowwise", None), data=None, **kw):
+    tr = Trainer(*setup, device=dev, seed=42, graph=graph, **kw)
+    x, y = data if data is not None else (X, Y)
     tr.model.eval()                                      # no dropout in the dense model anyway; keeps BN-free determinism explicit
     step = tr.step_graphed if graph else tr.step
     losses = [float(step(x, y).detach()) for _ in range(steps)]
@@ -61,6 +62,26 @@ for name, kw in variants.items():
         assert tr.dp.overlap and len(tr.dp._ranges) > 2, "the async hook path needs several sub-buckets"
     base = refb if kw.get("batched") else ref
     out[name] = {"max_param_diff": diff(params, base), "losses": losses, "buckets": len(tr.dp._ranges)}
+if not ONLY_CAPTURED_COLLECTIVES:
+    # Exact mode B with gradients that are NOT dy: the loss term of "nqcl" and the l2 regularisers of the
+    # ResNet-18-like net are applied after the scale gradients were recomputed from the pure task-loss P.grad, so the
+    # one-rank data-parallel step reproduces the single-process step.
+    nqcl = ("mnist", "nqcl", (2e-4, 1e-3), "rowwise", "maxbin")
+    _, l0, p0 = run(setup=nqcl, batched=True)
+    for name, kw in (("nqcl_B_batched", dict(ddp_mode="B", batched=True, force_collectives=True)),
+                     ("nqcl_A_batched", dict(ddp_mode="A", batched=True, force_collectives=True))):
+        tr, l1, p1 = run(setup=nqcl, **kw)
+        out[name] = {"max_param_diff": diff(p1, p0), "losses": l1, "ref_losses": l0}
+    # the penalty must matter in this comparison: without it the scales end elsewhere
+    _, _, pn = run(setup=("mnist", "nq", 2e-4, "rowwise", None), batched=True)
+    out["nqcl_vs_nq_scale_diff"] = max(float((p0[k] - pn[k]).abs().max()) for k in p0 if "scale" in k)
+    res18 = ("imagenette", "nq", 1e-11, "channelwise", None)
+    d18 = synthetic_batch("imagenette", 2, dev, torch.Generator(device=dev).manual_seed(1))
+    tr0, l0, p0 = run(setup=res18, data=d18, steps=2, batched=True)
+    assert tr0.regularized, "the ResNet-18-like net carries l2 regularisers"
+    _, _, p0b = run(setup=res18, data=d18, steps=2, batched=True)       # MIOpen's weight-gradient kernels may not be run-to-run stable
+    tr, l1, p1 = run(setup=res18, data=d18, steps=2, ddp_mode="B", batched=True, force_collectives=True)
+    out["B_batched_regularized_resnet18"] = {"max_param_diff": diff(p1, p0), "ref_self_diff": diff(p0b, p0), "losses": l1, "ref_losses": l0}
 # graphed steps against their eager data-parallel counterparts
 graphed = {"graph_split_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True),
            "graph_split_B_batched": dict(ddp_mode="B", batched=True, force_collectives=True),
