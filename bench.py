@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--event-every", type=int, default=0, help="(ignored: the roofline leg now runs after the timed loop)")
     ap.add_argument("--graph", action="store_true", help="replay the steps from captured hipGraphs of --graph-steps steps each "
                     "(with torch.distributed: the scale-gradient all-reduce sits on a forked branch of the graph)")
+    ap.add_argument("--graph-edges", choices=["fork_join", "fork_only", "linear"], default="fork_join",
+                    help="captured exchange: fork_join = all-reduce on a side branch joined before its buffer is rewritten two steps "
+                         "later; fork_only = one gradient buffer per step of the graph, side branches joined once at the end of the "
+                         "graph; linear = the all-reduce in the compute chain (no cross-branch edge, its latency exposed)")
     ap.add_argument("--graph-steps", type=int, default=8, help="steps per captured graph (a multiple of the buffer sets keeps the rotation)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the informational extra measurements (N=1 only)")
@@ -168,7 +172,7 @@ def main():
         outer, G, inner = 1, 1, ELEMS
     # two gradient buffers: the (tiny) scale-gradient all-reduce of step i runs asynchronously on RCCL's
     # stream and overlaps the kernels of step i+1; a buffer is reused only after its collective completed
-    dss = [torch.zeros_like(s), torch.zeros_like(s)]
+    dss = [torch.zeros_like(s) for _ in range(max(2, args.graph_steps if args.graph_edges == "fork_only" else 2))]
     ds = dss[0]
     pending = [None, None]
     ws_bytes = lib.lq_workspace_bytes(outer, G, inner)
@@ -262,28 +266,33 @@ def main():
         with torch.cuda.graph(gph, stream=cap, capture_error_mode="thread_local" if use_dist else "global"):
             main = torch.cuda.current_stream(dev)
             cs = main.cuda_stream or None
+            edges = args.graph_edges if use_dist else "linear"
             for j in range(S):
-                k, b = j % nsets, j & 1
+                k = j % nsets
+                b = j if edges == "fork_only" else (j & 1)             # fork_only: a gradient buffer per step, no join until the end
+                side = sides[j & 1]
+                join = use_dist and edges == "fork_join" and j >= 2    # the all-reduce of step j-2 is done with dss[b]
                 if args.variant == "split":
                     rc = fwd(px[k], ps, pout[k], None, 0, outer, G, inner, cs)
-                    if use_dist and j >= 2:
-                        main.wait_stream(sides[b])         # join: the all-reduce of step j-2 is done with dss[b]
+                    if join:
+                        main.wait_stream(side)
                     rc |= bwd(px[k], ps, pdy[k], lam, pdss[b], None, pws, ws_bytes, outer, G, inner, cs)
                 else:
-                    if use_dist and j >= 2:
-                        main.wait_stream(sides[b])
+                    if join:
+                        main.wait_stream(side)
                     rc = fused(px[k], ps, pdy[k], lam, pout[k], pdss[b], pws, ws_bytes, outer, G, inner, cs)
                 if rc:
                     _hip.check(rc, "graph capture")
                 if use_dist:
-                    sides[b].wait_stream(main)             # fork
-                    with torch.cuda.stream(sides[b]):
+                    if edges != "linear":
+                        side.wait_stream(main)                         # fork
+                    with torch.cuda.stream(side if edges != "linear" else main):
                         if avg_op is not None:
                             dist.all_reduce(dss[b], op=avg_op)
                         else:
                             dss[b].div_(world)
                             dist.all_reduce(dss[b], op=dist.ReduceOp.SUM)
-            if use_dist:
+            if use_dist and edges != "linear":
                 main.wait_stream(sides[0])
                 main.wait_stream(sides[1])
         return gph
@@ -491,7 +500,7 @@ def main():
                        "per_gpu_batch": BATCH, "global_batch": BATCH * world, "parallelism": f"dp{world}",
                        "buffer_sets": nsets, "algorithmic_bytes_per_step": step_bytes,
                        "launch": (f"hipGraph of {max(graphs)} steps" if graphs is not None else "eager"),
-                       "exchange": ({"graph": "RCCL all-reduce of ds captured on a forked branch of the step graph",
+                       "exchange": ({"graph": f"RCCL all-reduce of ds captured in the step graph ({args.graph_edges})",
                                      "sync": "eager all-reduce of ds on the compute stream",
                                      "async": "eager all-reduce of ds on RCCL's stream"}.get(exchange_form) if use_dist else None),
                        **({"note": graph_note} if graph_note else {}),

@@ -170,7 +170,7 @@ typedef struct lq_tensor_desc {
     const float* P;      /* parameter, contiguous fp32                          */
     const float* s;      /* scale [G]                                            */
     const float* dy;     /* default upstream gradient (may be NULL)              */
-    float* out;          /* fake-quantised output                                */
+    float* out;          /* fake-quantised output (may be NULL next to out_oihw when lq_conv_tile_supported) */
     float* ds;           /* scale gradient [G] (required when lambda is finite)  */
     float* m;            /* Adam first moment of the scale [G] or NULL           */
     float* v;            /* Adam second moment of the scale [G] or NULL          */
@@ -253,7 +253,11 @@ int lq_selftest_uniform_division(uint64_t seed, uint32_t blocks, uint32_t pairs_
  *                          (same traversal, same summation order: bit-identical) and writes dP = dy in HWIO order.
  * hw = kh*kw; hw*ci*co must equal outer*G*inner.  Weight-sized tensors (below 2^32 elements).
  * Kernels of at most 9 taps with co % 4 == 0 and one of the reference's four orientations run as LDS tiles (whole 128-byte
- * lines on both the HWIO and the OIHW side); lq_fq_scale_grad_oihw then needs lq_conv_workspace_bytes() of scratch.      */
+ * lines on both the HWIO and the OIHW side); lq_fq_scale_grad_oihw then needs lq_conv_workspace_bytes() of scratch.
+ * When the OIHW tensor is the only consumer (tf.nn.conv2d(x, qk) at custom_layers.py:340-348 is the kernel's ONLY use in a
+ * training step), `out` may be NULL for kernels the tile path takes -- lq_conv_tile_supported() == 1 and P 16-byte aligned:
+ * the forward then moves 8 bytes per element instead of 12.                                                             */
+int lq_conv_tile_supported(int64_t hw, int64_t ci, int64_t co, int64_t outer, int64_t G, int64_t inner);
 size_t lq_conv_workspace_bytes(int64_t hw, int64_t ci, int64_t co, int64_t outer, int64_t G, int64_t inner);
 int lq_fq_forward_oihw(const float* P, const float* s, float* out, float* out_oihw, int64_t hw, int64_t ci, int64_t co,
                        int64_t outer, int64_t G, int64_t inner, void* stream);

@@ -67,6 +67,7 @@ SIGNATURES.update({
     "lq_batch_scale_grad": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
     "lq_batch_scale_grad_oihw": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
     "lq_conv_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
+    "lq_conv_tile_supported": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "lq_fq_forward_oihw": (_c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "lq_fq_scale_grad_oihw": (_c_int, [_c_p, _c_p, _c_p, _c_f, _c_p, _c_p, _c_p, _c_sz, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     "lq_batch_scale_adam": (_c_int, [_c_p, _c_d, _c_d, _c_d, _c_d, _c_i64, _c_p, _c_int, _c_p]),
@@ -92,7 +93,10 @@ class LQError(RuntimeError):
 
 def load() -> ctypes.CDLL:
     """Loads liblq_hip.so, binds every prototype and runs the device self-test.  Raises loudly if the library is absent;
-    a failed self-test is remembered and re-raised by EVERY later call (the library is never handed out unverified)."""
+    a failed self-test is remembered and re-raised by EVERY later call.  The self-test needs a visible GPU and must not run
+    inside a stream capture: while either holds the library is handed out with the test still pending (CPU-side argument
+    validation, calls recorded into a hipGraph) and every later call retries it -- the first call that can run it does, so no
+    kernel result leaves a process whose device/compiler combination fails the test."""
     global _lib, _pending
     if _selftest_error is not None:
         raise RuntimeError(_selftest_error)

@@ -28,12 +28,16 @@ from .layers import CustomDenseLayer, _ConvBase, custom_layers_of
 
 
 class _Entry:
-    __slots__ = ("layer", "slot", "param", "nested", "out", "ds", "m", "v", "desc", "out_oihw", "dp", "conv")
+    __slots__ = ("layer", "slot", "param", "nested", "out", "ds", "m", "v", "desc", "out_oihw", "dp", "conv", "shape")
 
 
 class FakeQuantBatch:
     def __init__(self, model_or_layers, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-7, mode: str = "keras",
-                 oihw: bool = True):
+                 oihw: bool = True, hwio_out: bool = True):
+        """``oihw``: conv kernels of nested-quantization layers get an OIHW companion output (what MIOpen consumes).
+        ``hwio_out=False``: where the LDS-tile kernel writes that companion, the HWIO output is not materialised at all -- in a
+        training step the convolution is the kernel's only consumer (custom_layers.py:340-348), so the forward moves 8 bytes
+        per element instead of 12; ``quantize_all()`` then returns the HWIO tensor as a permuted VIEW of the companion."""
         layers = custom_layers_of(model_or_layers) if isinstance(model_or_layers, torch.nn.Module) else list(model_or_layers)
         self.layers = layers
         self._external_grads = False
@@ -56,6 +60,7 @@ class FakeQuantBatch:
                 if not param.data.is_contiguous():
                     raise ValueError("parameters must be contiguous")
                 e.out = torch.empty_like(param.data)
+                e.shape = tuple(param.shape)
                 # write straight into an existing gradient buffer (e.g. a DataParallel bucket view) when there is one
                 g = nested.scale.grad
                 if g is not None and g.is_contiguous():
@@ -75,6 +80,9 @@ class FakeQuantBatch:
                     e.conv = (kh * kw, ci, co)
                     e.out_oihw = torch.empty((co, ci, kh, kw), dtype=torch.float32, device=param.device)
                     e.dp = torch.empty_like(param.data)
+                    if (not hwio_out and param.data_ptr() % 16 == 0
+                            and _hip.load().lq_conv_tile_supported(kh * kw, ci, co, *e.desc) == 1):
+                        e.out = None               # the companion is the only forward output of this tensor
                 self.entries.append(e)
         if not self.entries:
             raise ValueError("no custom layers")
@@ -85,7 +93,7 @@ class FakeQuantBatch:
         for i, e in enumerate(self.entries):
             lam = e.nested.penalty_threshold
             c = getattr(e.nested.scale, "lq_constraint", None)
-            arr[i] = _hip.TensorDesc(e.param.data_ptr(), e.nested.scale.data_ptr(), None, e.out.data_ptr(), e.ds.data_ptr(),
+            arr[i] = _hip.TensorDesc(e.param.data_ptr(), e.nested.scale.data_ptr(), None, _hip.ptr(e.out), e.ds.data_ptr(),
                                      e.m.data_ptr(), e.v.data_ptr(), e.desc[0], e.desc[1], e.desc[2],
                                      float("nan") if lam is None else float(lam),
                                      float(c.min_value) if c is not None else float("-inf"),
@@ -205,7 +213,9 @@ class _BatchFn(torch.autograd.Function):
         ctx.batch = batch
         ctx.set_materialize_grads(False)        # an output nobody consumed arrives as None in backward, not as a zero tensor
         # fresh tensor objects over the static buffers: every HWIO output, then the OIHW companions of the conv kernels
-        return tuple(e.out.detach() for e in batch.entries) + tuple(batch.entries[i].out_oihw.detach() for i in batch._oihw_idx)
+        # (a tensor without a materialised HWIO output hands out the HWIO-shaped permuted view of its companion)
+        return tuple(e.out.detach() if e.out is not None else e.out_oihw.detach().permute(2, 3, 1, 0) for e in batch.entries) \
+            + tuple(batch.entries[i].out_oihw.detach() for i in batch._oihw_idx)
 
     @staticmethod
     def backward(ctx, *dys):
@@ -228,7 +238,7 @@ class _BatchFn(torch.autograd.Function):
                 d = dys[i]
                 if d is None and i in batch._oihw_pos and dys[batch._oihw_pos[i]] is not None:
                     d = dys[batch._oihw_pos[i]].permute(2, 3, 1, 0)
-                grads.extend((d if d is not None else torch.zeros_like(e.out), None))
+                grads.extend((d if d is not None else torch.zeros_like(e.param.data), None))
             return tuple(grads)
         keep = []
         gathered = set()
@@ -238,7 +248,7 @@ class _BatchFn(torch.autograd.Function):
                 d = dys[batch._oihw_pos[i]]
                 gathered.add(i)
             elif d is None:
-                d = torch.zeros_like(e.out)
+                d = torch.zeros_like(e.param.data)
             elif oihw_used and i in batch._oihw_pos:
                 raise RuntimeError("FakeQuantBatch: conv kernels must all be consumed through the same layout in one step")
             d = _hip.require_device_f32(d, "dy")

@@ -149,7 +149,7 @@ __device__ __forceinline__ void conv_tile_fwd(const Params& p, const ConvTile& c
                 const uint32_t idx = (ct_pass_h(ct, q) * ct.ci + g.c0 + crel) * ct.co + g.o0 + 4 * g.o4;
                 if (q == 0 || ct_pass_new(ct, q)) ctx = O::ctx_of(p, sc[q]);      // block-uniform condition
                 if (!LQ_ABLATE(1)) x[q] = O::elem4(p, ctx, idx, x[q], x[q], none);      // the outputs take the inputs' registers
-                if (!LQ_ABLATE(4)) store4<0>(p.out + idx, x[q]);
+                if (p.out && !LQ_ABLATE(4)) store4<0>(p.out + idx, x[q]);        // block-uniform: the HWIO output is optional
             }
         }
     }

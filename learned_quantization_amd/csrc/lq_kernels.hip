@@ -977,8 +977,9 @@ int lq_fq_forward_oihw(const float* P, const float* s, float* out, float* out_oi
     if ((rc = check_conv("lq_fq_forward_oihw", hw, ci, co, outer, G, inner))) return rc;
     LQ_REQUIRE_PTR(P);
     LQ_REQUIRE_PTR(s);
-    LQ_REQUIRE_PTR(out);
     LQ_REQUIRE_PTR(out_oihw);
+    if (!out && !(aligned(P, 16) && lq_conv_tile_supported(hw, ci, co, outer, G, inner)))
+        return fail(LQ_EINVAL, "lq_fq_forward_oihw: out may be NULL only for kernels the LDS-tile path takes (lq_conv_tile_supported) with P 16-byte aligned");
     Plan pl = make_plan(outer, G, inner);
     Params p = base_params(P, s, outer, G, inner);
     p.out = out;
@@ -992,6 +993,13 @@ int lq_fq_forward_oihw(const float* P, const float* s, float* out, float* out_oi
         return check_hip("conv tile forward launch");
     }
     return launch_traverse<OP_FWD_PERM>(pl, p, (hipStream_t)stream);      // element-wise companion (kernels with > 9 taps, co % 4 != 0, ...)
+}
+
+int lq_conv_tile_supported(int64_t hw, int64_t ci, int64_t co, int64_t outer, int64_t G, int64_t inner) {
+    if (outer <= 0 || G <= 0 || inner <= 0 || hw <= 0 || ci <= 0 || co <= 0) return 0;
+    if ((double)hw * (double)ci * (double)co != (double)outer * (double)G * (double)inner) return 0;
+    ConvTile ct;
+    return make_conv_tile(ct, hw, ci, co, outer, G, inner) ? 1 : 0;
 }
 
 size_t lq_conv_workspace_bytes(int64_t hw, int64_t ci, int64_t co, int64_t outer, int64_t G, int64_t inner) {
@@ -1523,7 +1531,11 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
     for (int i = 0; i < n && !rc; ++i) {
         const lq_tensor_desc& d = descs[i];
         rc = check_desc(d.outer, d.G, d.inner);
-        if (!rc && (!d.P || !d.s || !d.out)) rc = fail(LQ_EINVAL, "lq_batch_create: tensor %d has a NULL P/s/out", i);
+        // `out` (HWIO) is optional for a conv kernel whose OIHW companion is the only consumer, where the LDS tile serves it
+        const bool out_optional = !rc && d.conv_co > 0 && d.out_oihw && aligned(d.P, 16) &&
+                                  lq_conv_tile_supported(d.conv_hw, d.conv_ci, d.conv_co, d.outer, d.G, d.inner);
+        if (!rc && (!d.P || !d.s || (!d.out && !out_optional)))
+            rc = fail(LQ_EINVAL, "lq_batch_create: tensor %d has a NULL P/s/out (out may be NULL only next to an out_oihw the LDS-tile path writes)", i);
         if (!rc && (!aligned(d.P, 4) || !aligned(d.s, 4) || !aligned(d.out, 4))) rc = fail(LQ_EALIGN, "lq_batch_create: tensor %d misaligned", i);
         if (!rc && d.conv_co > 0) {
             rc = check_conv("lq_batch_create", d.conv_hw, d.conv_ci, d.conv_co, d.outer, d.G, d.inner);

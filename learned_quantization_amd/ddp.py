@@ -164,9 +164,11 @@ class DataParallel:
                 hi, cur_params = cur_lo, []
         self._remaining = list(self._pending_count)
         self._launched = [False] * len(self._ranges)
-        if self.overlap:
-            for i, p in enumerate(self.bucket.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+        # the hooks are registered in every configuration: with overlap they launch a sub-bucket's all-reduce as soon as it is
+        # complete; without (graphed steps, overlap=False) they still count arrivals, so a second backward into an already
+        # exchanged bucket raises in every mode
+        for i, p in enumerate(self.bucket.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     def __call__(self, *a, **k):
         return self.module(*a, **k)
@@ -200,7 +202,7 @@ class DataParallel:
                                    "backward without dp.zero_grad().  For gradient accumulation run the earlier backward "
                                    "passes under `with dp.no_sync():`")
             self._remaining[b] -= 1
-            if self._remaining[b] == 0:
+            if self._remaining[b] == 0 and self.overlap:
                 self._launch(b)
         return hook
 

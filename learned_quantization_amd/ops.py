@@ -217,9 +217,11 @@ def _conv_extents(shape):
     return kh * kw, ci, co
 
 
-def fq_forward_oihw(kernel: torch.Tensor, scale: torch.Tensor):
+def fq_forward_oihw(kernel: torch.Tensor, scale: torch.Tensor, hwio_out: bool = True):
     """K1 on an HWIO conv kernel (custom_layers.py:321, 340) that also emits the OIHW tensor MIOpen consumes: returns
-    (out_hwio, out_oihw) with out_oihw == out_hwio.permute(3, 2, 0, 1) bit for bit, in ONE launch (no transpose kernel)."""
+    (out_hwio, out_oihw) with out_oihw == out_hwio.permute(3, 2, 0, 1) bit for bit, in ONE launch (no transpose kernel).
+    ``hwio_out=False``: where the LDS-tile kernel takes the tensor, only the OIHW tensor is written (8 bytes per element
+    instead of 12) and out_hwio is the permuted view of it."""
     lib = _hip.load()
     p = _hip.require_device_f32(kernel, "kernel")
     s = _hip.require_device_f32(scale, "scale")
@@ -227,11 +229,12 @@ def fq_forward_oihw(kernel: torch.Tensor, scale: torch.Tensor):
         raise ValueError("fq_forward_oihw needs an HWIO conv kernel (kh, kw, ci, co)")
     hw, ci, co = _conv_extents(p.shape)
     outer, G, inner = _desc(p, s)
-    out = torch.empty_like(p)
+    companion_only = (not hwio_out) and p.data_ptr() % 16 == 0 and lib.lq_conv_tile_supported(hw, ci, co, outer, G, inner) == 1
+    out = None if companion_only else torch.empty_like(p)
     out_oihw = torch.empty((co, ci, p.shape[0], p.shape[1]), dtype=torch.float32, device=p.device)
     _hip.check(lib.lq_fq_forward_oihw(_hip.ptr(p), _hip.ptr(s), _hip.ptr(out), _hip.ptr(out_oihw), hw, ci, co,
                                       outer, G, inner, _hip.stream_ptr(p.device)), "lq_fq_forward_oihw")
-    return out, out_oihw
+    return (out if out is not None else out_oihw.permute(2, 3, 1, 0)), out_oihw
 
 
 def fq_scale_grad_oihw(kernel: torch.Tensor, scale: torch.Tensor, dy_oihw: torch.Tensor, penalty_threshold: float):
@@ -264,7 +267,7 @@ class _NestedQuantConvFn(torch.autograd.Function):
         ctx.save_for_backward(kernel, scale)
         ctx.penalty_threshold = float(penalty_threshold)
         ctx.defer = bool(defer_scale_grad)
-        return fq_forward_oihw(kernel, scale)[1]
+        return fq_forward_oihw(kernel, scale, hwio_out=False)[1]
 
     @staticmethod
     def backward(ctx, dy_oihw):

@@ -54,13 +54,15 @@ class Trainer:
     A step is two phases: ``_backward_phase`` (zero the gradients, fake-quantise, forward, loss, backward, penalty
     injection) and ``_update_phase`` (exact-mode scale gradients, both optimizers); between them the data-parallel
     exchange.  ``graph=True`` records the phases into hipGraphs: one graph for the whole step on one GPU; with
-    ``world_size > 1`` either graph(backward) -> eager bucketed all-reduce -> graph(update) (default), or -- with
-    ``graph_collectives=True`` -- ONE graph that contains the RCCL all-reduce as well (RCCL kernels are capturable).
+    ``world_size > 1`` ONE graph that contains the RCCL all-reduce as well (RCCL kernels are capturable; the default on
+    backend "nccl": 118.7 k against 109.6 k images/s for the CIFAR step on a one-rank communicator, profiles/r02_e2e.jsonl),
+    or graph(backward) -> eager bucketed all-reduce -> graph(update) (``graph_collectives=False``, other backends, and the
+    fallback when the capture of the collective fails).
     """
 
     def __init__(self, config="cifar", mode="nq", value=1e-11, orientation="channelwise", loss: Optional[str] = None,
                  lr=1e-4, seed=42, device=None, ddp_mode="A", log_dir="logs", graph=False, batched=False,
-                 bucket_mb: float = 25.0, overlap: bool = True, graph_collectives: bool = False,
+                 bucket_mb: float = 25.0, overlap: bool = True, graph_collectives: Optional[bool] = None,
                  force_collectives: bool = False):
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         torch.manual_seed(seed)
@@ -100,7 +102,7 @@ class Trainer:
             from .batch import BatchedScaleAdam, FakeQuantBatch
             if self.dp is not None:
                 self.dp.zero_grad()          # makes scale.grad the bucket views the batch will write into
-            self.batch = FakeQuantBatch(self.model, lr=lr)
+            self.batch = FakeQuantBatch(self.model, lr=lr, hwio_out=False)     # the convolutions consume the OIHW companions only
             self.scale_opt = BatchedScaleAdam(self.batch, capturable=graph)
             if self.dp is not None:
                 self.dp.attach_batch(self.batch)
@@ -109,7 +111,10 @@ class Trainer:
         self.regularized = [l for l in self.custom_layers if l.regularizer is not None]
         self.graph = None
         self.graph_update = None
+        if graph_collectives is None:          # default: capture the collective where the backend can be captured
+            graph_collectives = bool(use_dp and dist.get_backend() == "nccl")
         self.graph_collectives = graph_collectives
+        self.graph_note = None
         self._want_graph = graph
 
     def loss(self, y, p):
@@ -179,6 +184,25 @@ class Trainer:
             out = fn()
         return g, out
 
+    def _capture_whole_step(self) -> bool:
+        """ONE graph: backward phase, RCCL all-reduce (synchronous collectives on the capturing stream), update phase.
+        Returns False -- and leaves the trainer ready for the split form -- when the stack refuses to capture the collective."""
+        def whole():
+            loss = self._backward_phase(self._x, self._y)
+            self.dp.exchange(capture_safe=True)
+            self._update_phase()
+            return loss
+        try:
+            self.graph, self._loss = self._capture(whole)
+            return True
+        except Exception as e:
+            self.graph = None
+            self.graph_collectives = False
+            self.graph_note = f"the collective could not be captured ({e!r}"[:200] + "): graph / eager all-reduce / graph"
+            torch.cuda.synchronize(self.device)
+            self.dp.begin_step()
+            return False
+
     def step_graphed(self, x, y):
         """The training step as hipGraph launches.  These steps are launch-bound (hundreds of small kernels); capture
         removes the host from the loop.  First call: 3 eager warm-up steps on a side stream, then capture.
@@ -201,13 +225,8 @@ class Trainer:
                 self.opt.zero_grad(set_to_none=True)
                 self.scale_opt.zero_grad(set_to_none=True)
                 self.graph, self._loss = self._capture(lambda: self.step(self._x, self._y))
-            elif self.graph_collectives:
-                def whole():
-                    loss = self._backward_phase(self._x, self._y)
-                    self.dp.exchange(capture_safe=True)
-                    self._update_phase()
-                    return loss
-                self.graph, self._loss = self._capture(whole)
+            elif self.graph_collectives and self._capture_whole_step():
+                pass
             else:
                 self.graph, self._loss = self._capture(lambda: self._backward_phase(self._x, self._y))
                 self.dp.exchange()
@@ -246,7 +265,10 @@ def main(argv=None):
     ap.add_argument("--ddp-mode", choices=["A", "B"], default="A")
     ap.add_argument("--export-dir", default=None, help="write the reference's integer export here at the end")
     ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs (N > 1: graph / all-reduce / graph)")
-    ap.add_argument("--graph-collectives", action="store_true", help="N > 1: capture the RCCL all-reduce inside ONE graph")
+    ap.add_argument("--graph-collectives", dest="graph_collectives", action="store_true", default=None,
+                    help="N > 1: capture the RCCL all-reduce inside ONE graph (the default on backend nccl)")
+    ap.add_argument("--no-graph-collectives", dest="graph_collectives", action="store_false",
+                    help="N > 1: graph(backward) -> eager bucketed all-reduce -> graph(update)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the collectives even with one rank (RCCL rehearsal on one GPU)")
     ap.add_argument("--bucket-mb", type=float, default=25.0)
     ap.add_argument("--backend", default="nccl", help="nccl = RCCL over xGMI (default); gloo + --share-gpu rehearses N>1 on one GPU")
@@ -316,7 +338,8 @@ def main(argv=None):
             "value": world * args.batch * args.steps / dt, "unit": "images/s", "n_gpus": world,
             "ms_per_step": dt / args.steps * 1e3, "per_gpu_batch": args.batch, "orientation": args.orientation,
             "loss_term": args.loss, "quantized_elements": n_q, "final_loss": float(loss.detach()), "ddp_mode": args.ddp_mode,
-            "hipgraph": bool(args.graph), "graph_collectives": bool(args.graph_collectives), "batched": bool(args.batched),
+            "hipgraph": bool(args.graph), "graph_collectives": bool(tr.graph_collectives and args.graph and use_dist),
+            **({"graph_note": tr.graph_note} if tr.graph_note else {}), "batched": bool(args.batched),
             "backend": (args.backend if use_dist else None),
             "channels_last": bool(args.channels_last)}))
         if args.export_dir:

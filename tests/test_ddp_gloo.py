@@ -151,6 +151,16 @@ def _accum_worker(rank, world, port, out_dir):
         res["second_backward"] = "no error"
     except RuntimeError as e:
         res["second_backward"] = str(e)
+    # ... also without overlap (the configuration of the graphed steps): the guard does not depend on the hooks launching anything
+    dp2 = DataParallel(_FakeLayer(2e-2), mode="A", scale_grad_fn=_oracle_scale_grad, overlap=False)
+    dp2.zero_grad()
+    ((dp2(xs) - ys) ** 2).sum().backward()
+    dp2.sync_gradients()
+    try:
+        ((dp2(xs) - ys) ** 2).sum().backward()
+        res["second_backward_no_overlap"] = "no error"
+    except RuntimeError as e:
+        res["second_backward_no_overlap"] = str(e)
     # (2) gradient accumulation: earlier passes under no_sync(), the last one exchanges the accumulated bucket
     dp.zero_grad()
     with dp.no_sync():
@@ -168,6 +178,7 @@ def test_gradient_accumulation_and_double_backward_guard(tmp_path):
     mp.spawn(_accum_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = torch.load(tmp_path / "acc0.pt"), torch.load(tmp_path / "acc1.pt")
     assert "no_sync" in r0["second_backward"] and "no_sync" in r1["second_backward"]
+    assert "no_sync" in r0["second_backward_no_overlap"] and "no_sync" in r1["second_backward_no_overlap"]
     assert torch.equal(r0["W_accum"], r1["W_accum"])
     # reference: mean over ranks of the per-rank summed-loss gradients
     sys.path.insert(0, ROOT)

@@ -195,6 +195,8 @@ def test_oihw_companion_ops_are_bit_identical_to_permuting(dev, orient):
         ref = lq.fq_forward(k, s)
         assert torch.equal(out, ref), f"{shape} {orient}: HWIO output"
         assert out_oihw.is_contiguous() and torch.equal(out_oihw, ref.permute(3, 2, 0, 1)), f"{shape} {orient}: OIHW companion"
+        view, only = ops.fq_forward_oihw(k, s, hwio_out=False)          # the companion alone (the autograd op's form)
+        assert torch.equal(only, out_oihw) and torch.equal(view, ref), f"{shape} {orient}: companion-only forward"
         _, out_o = O.fq_forward(k.cpu().numpy(), s.cpu().numpy())
         np.testing.assert_array_equal(out_oihw.cpu().numpy(), np.transpose(out_o, (3, 2, 0, 1)))
         dy_oihw = torch.tensor((rng.normal(0, 1, size=out_oihw.shape) * 10.0 ** rng.uniform(-8, -2, size=out_oihw.shape)).astype(np.float32), device=dev)
@@ -226,14 +228,21 @@ def test_conv_layer_hands_miopen_the_oihw_companion(dev):
     assert layer.nested_q_k_layer.scale.grad is not None and bool((layer.nested_q_k_layer.scale.grad <= 0).all())
 
 
-def test_batch_emits_oihw_companions_and_reads_oihw_gradients(dev):
+@pytest.mark.parametrize("hwio_out", [True, False])
+def test_batch_emits_oihw_companions_and_reads_oihw_gradients(dev, hwio_out):
     """FakeQuantBatch on a conv model: one forward launch emits every OIHW companion, one scale-gradient launch gathers every
-    OIHW weight gradient and writes dP in HWIO order -- bit-identical to the single-tensor ops on the permuted tensors."""
+    OIHW weight gradient and writes dP in HWIO order -- bit-identical to the single-tensor ops on the permuted tensors.
+    ``hwio_out=False`` (the trainer's form): the HWIO output is not materialised where the LDS tile writes the companion; the
+    batch hands out the permuted view of the companion in its place."""
     import learned_quantization_amd as lq
     m = _model(dev, "cifar", "channelwise")
-    batch = lq.FakeQuantBatch(m)
+    batch = lq.FakeQuantBatch(m, hwio_out=hwio_out)
+    assert hwio_out or sum(e.out is None for e in batch.entries) == 6, "every 3x3 kernel of the CIFAR CNN takes the tile path"
     batch.quantize_all()
     layers = lq.custom_layers_of(m)
+    for l in layers:                    # against the single-tensor forward
+        assert torch.equal(l._q_pre[0], lq.fq_forward(l.kernel.data, l.nested_q_k_layer.scale.data))
+        assert l._q_pre[0].is_contiguous() == hwio_out
     g = torch.Generator(device=dev).manual_seed(9)
     outs, dys = [], []
     for l in layers:

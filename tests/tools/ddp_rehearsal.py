@@ -83,11 +83,11 @@ if not ONLY_CAPTURED_COLLECTIVES:
     tr, l1, p1 = run(setup=res18, data=d18, steps=2, ddp_mode="B", batched=True, force_collectives=True)
     out["B_batched_regularized_resnet18"] = {"max_param_diff": diff(p1, p0), "ref_self_diff": diff(p0b, p0), "losses": l1, "ref_losses": l0}
 # graphed steps against their eager data-parallel counterparts
-graphed = {"graph_split_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True),
-           "graph_split_B_batched": dict(ddp_mode="B", batched=True, force_collectives=True),
-           "graph_split_A": dict(ddp_mode="A", force_collectives=True)}
+graphed = {"graph_split_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True, graph_collectives=False),
+           "graph_split_B_batched": dict(ddp_mode="B", batched=True, force_collectives=True, graph_collectives=False),
+           "graph_split_A": dict(ddp_mode="A", force_collectives=True, graph_collectives=False)}
 if ONLY_CAPTURED_COLLECTIVES:      # its own process: a collective that cannot be captured on this stack aborts the process group
-    graphed = {"graph_collectives_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True, graph_collectives=True),
+    graphed = {"graph_collectives_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True),      # the default on RCCL
                "graph_collectives_B_batched": dict(ddp_mode="B", batched=True, force_collectives=True, graph_collectives=True)}
 for name, kw in graphed.items():
     try:
@@ -99,7 +99,7 @@ for name, kw in graphed.items():
         rels = {k: float((params[k] - ep[k]).abs().max() / ep[k].abs().max()) for k in params}     # per tensor, against its magnitude
         worst = max(rels, key=rels.get)
         out[name] = {"max_rel_param_diff_vs_eager": rels[worst], "worst_tensor": worst, "losses": losses, "eager_losses": el,
-                     "graphs": 1 + (tr.graph_update is not None)}
+                     "graphs": 1 + (tr.graph_update is not None), "note": tr.graph_note}
     except Exception as e:                               # reported, judged by the test
         out[name] = {"error": repr(e)[:300]}
 print("REHEARSAL " + json.dumps(out))

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--only", default=None, help="config:orientation, e.g. mnist:columnwise")
     ap.add_argument("--abi-only", action="store_true", help="time only the raw batch ABI (profiling runs)")
+    ap.add_argument("--companion-only", action="store_true", help="conv kernels emit the OIHW companion only (hwio_out=False: what the trainer uses)")
     ap.add_argument("--ablate", type=int, default=0, help="development library only (LQ_HIP_LIB=.../liblq_hip_dev.so): lq_dev_set_ablate mask")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -55,10 +56,10 @@ def main():
             # resnet50 (BASELINE configs[4], 108 tensors, 23.5 M el): "mixed" thresholds, 1e-10 on the 3x3 kernels, 1e-11 elsewhere
             model = lq.build_model(config, mode="nq", value=(1e-10, lam) if config == "resnet50" else lam, seed=42,
                                    orientation=orient, device=dev)
-            batch = lq.FakeQuantBatch(model)
+            batch = lq.FakeQuantBatch(model, hwio_out=not args.companion_only)
             opt = lq.BatchedScaleAdam(batch)
             g = torch.Generator(device=dev).manual_seed(42)
-            dys = [torch.randn(e.out.shape, device=dev, generator=g) * 1e-3 for e in batch.entries]
+            dys = [torch.randn(e.shape, device=dev, generator=g) * 1e-3 for e in batch.entries]
             n_el = sum(e.param.numel() for e in batch.entries)
 
             def batched_step():
@@ -97,6 +98,7 @@ def main():
                 lib.lq_batch_scale_adam(batch._handle, 1e-4, 0.9, 0.999, 1e-7, 1, None, 0, sp)
 
             row = {"config": config, "orientation": orient, "tensors": len(batch.entries), "elements": n_el,
+                   "companion_only": bool(args.companion_only),
                    "us_per_step_batched_abi": timed(batched_abi_only, args.steps, dev),
                    "us_per_step_batched_abi_oihw": timed(batched_abi_oihw, args.steps, dev)}
             if not args.abi_only:

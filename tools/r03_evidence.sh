@@ -38,6 +38,52 @@ cov)
   python3 tools/kernel_coverage.py $out/cov > $out/kernel_coverage.txt; echo "coverage rc=$?"
   find $out/cov -name "*kernel_trace.csv" -size +4M -delete
   head -n 60 $out/kernel_coverage.txt ;;
+exchange)
+  # the ds exchange of the bench step on a one-rank RCCL communicator: graph without / with the captured all-reduce, eager forms
+  for v in "--graph" "--graph --force-dist" "--force-dist --exchange sync" "--force-dist --exchange async" ""; do
+    n=$(echo "bench$v" | tr -d ' ' | tr '-' '_')
+    timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-extras $v > $out/$n.json 2> $out/$n.err || { tail -n 5 $out/$n.err; exit 1; }
+    python3 -c "import json,sys; l=json.load(open('$out/$n.json')); print('$n', round(l['ms_per_step']*1e3,2), 'us/step', l['config'].get('launch'), '|', l['config'].get('exchange'))"
+  done ;;
+exchange2)
+  # which cross-branch edges of the captured exchange cost what (one-rank RCCL communicator)
+  for v in "--graph" "--graph --force-dist --graph-edges fork_join" "--graph --force-dist --graph-edges fork_only" "--graph --force-dist --graph-edges linear" "--force-dist --exchange sync"; do
+    n=$(echo "bench$v" | tr -d ' ' | tr '-' '_')
+    timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-extras $v > $out/$n.json 2> $out/$n.err || { tail -n 5 $out/$n.err; exit 1; }
+    python3 -c "import json,sys; l=json.loads([x for x in open('$out/$n.json') if x.startswith('{')][-1]); print('$n', round(l['ms_per_step']*1e3,2), 'us/step', l['config'].get('launch'), '|', l['config'].get('exchange'))"
+  done
+  cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+  for e in fork_join linear; do
+    mkdir -p $out/trace_$e
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$e -- python3 bench.py --no-cpu-baseline --no-extras --graph --force-dist --graph-edges $e --steps 64 --warmup 16 > $out/trace_$e/run.log 2> $out/trace_$e/err.log || exit 1
+    python3 - $out/trace_$e <<'PY'
+import csv, glob, sys
+f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True))[-1]
+for r in list(csv.DictReader(open(f)))[:8]:
+    print("  ", r["Name"][:70], r["Calls"], round(float(r["AverageNs"]) / 1e3, 2))
+PY
+  done ;;
+timeline)
+  export LQ_HIP_LIB=$GRAFT_REPO_ROOT/learned_quantization_amd/csrc/liblq_hip_dev.so
+  for c in imagenette:channelwise resnet50:channelwise; do
+    for w in fwd bwd_oihw; do
+      n=$(echo "timeline_${c}_$w" | tr ':' '_')
+      timeout -k 10 200 python3 tools/block_timeline.py $c $w > $out/$n.txt 2> $out/$n.err || { tail -n 5 $out/$n.err; exit 1; }
+      head -n 2 $out/$n.txt
+    done
+  done
+  LQ_TIMELINE_HWIO_OUT=0 timeout -k 10 200 python3 tools/block_timeline.py imagenette:channelwise fwd > $out/timeline_imagenette_channelwise_fwd_companion_only.txt 2>> $out/timeline.err || exit 1
+  unset LQ_HIP_LIB ;;
+batchtests)
+  timeout -k 10 900 python3 -m pytest tests/test_gpu_batch.py tests/test_gpu_harness.py -q -m gpu -x -p no:cacheprovider > $out/pytest_batch.log 2>&1; rc=$?
+  tail -n 15 $out/pytest_batch.log; [ $rc -eq 0 ] || exit 1 ;;
+quick)
+  # wall-clock + rocprofv3 kernel stats of the batch ABI on the two ResNet sets, both forward forms
+  bash tools/prof_batch_quick.sh $out/quick imagenette:channelwise resnet50:channelwise || exit 1
+  bash tools/prof_batch_quick.sh $out/quick_companion_only imagenette:channelwise resnet50:channelwise -- --companion-only || exit 1 ;;
+newtests)
+  timeout -k 10 900 python3 -m pytest tests/test_gpu_ddp.py tests/test_gpu_layers.py -q -m gpu -x -p no:cacheprovider > $out/pytest_new.log 2>&1; rc=$?
+  tail -n 15 $out/pytest_new.log; [ $rc -eq 0 ] || exit 1 ;;
 bench)
   timeout -k 10 400 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err || exit 1
   cat $out/bench_default.json ;;
