@@ -65,10 +65,12 @@ def parse():
     ap.add_argument("--event-every", type=int, default=0, help="(ignored: the roofline leg now runs after the timed loop)")
     ap.add_argument("--graph", action="store_true", help="replay the steps from captured hipGraphs of --graph-steps steps each "
                     "(with torch.distributed: the scale-gradient all-reduce sits on a forked branch of the graph)")
-    ap.add_argument("--graph-edges", choices=["fork_join", "fork_only", "linear"], default="fork_join",
-                    help="captured exchange: fork_join = all-reduce on a side branch joined before its buffer is rewritten two steps "
-                         "later; fork_only = one gradient buffer per step of the graph, side branches joined once at the end of the "
-                         "graph; linear = the all-reduce in the compute chain (no cross-branch edge, its latency exposed)")
+    ap.add_argument("--graph-edges", choices=["fork_join", "fork_only", "linear"], default="linear",
+                    help="captured exchange: linear = the all-reduce in the compute chain of the graph (default: no cross-branch edge, no "
+                         "event traffic; +2.5 us per step on a one-rank communicator); fork_join = all-reduce on a side branch joined before "
+                         "its buffer is rewritten two steps later (+17 us per step: a cross-branch edge of a hipGraph costs as much as the "
+                         "eager event pair); fork_only = one gradient buffer per step, side branches joined once at the end of the graph "
+                         "(+20 us).  profiles/r03/exchange/")
     ap.add_argument("--graph-steps", type=int, default=8, help="steps per captured graph (a multiple of the buffer sets keeps the rotation)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the informational extra measurements (N=1 only)")
@@ -242,12 +244,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- the graphed form.  A captured graph holds S consecutive steps; with torch.distributed the all-reduce of step j's
-    # scale gradient sits on a FORKED branch (one side stream per gradient buffer) that is joined right before the launch
-    # that rewrites that buffer two steps later -- inside a graph the cross-stream edges are graph dependencies, they cost
-    # no event traffic (the eager async form pays ~27 us per step for them), and the collective of step j runs under the
-    # kernels of steps j+1 and j+2 (the exchange overlaps the backward of the other layers; custom_layers.py:116-118).
-    # Only the collectives of a graph's last two steps are exposed: one small all-reduce per S steps.
+    # ---- the graphed form.  A captured graph holds S consecutive steps, each followed by the all-reduce of its scale gradient
+    # (custom_layers.py:116-118) in the SAME chain: captured, the collective is RCCL's kernel alone -- none of
+    # the event records ProcessGroupNCCL puts around an eager call (eager sync: +10 us per step on a one-rank communicator,
+    # eager async: +27 us; captured: +2.5 us, the one-rank reduce kernel itself).  Putting the collective on a forked
+    # branch of the graph (--graph-edges fork_join / fork_only) would hide its latency at N > 1 but costs 17-20 us per
+    # step here: hipGraph executes parallel branches on separate queues and every cross-branch edge is a signal between
+    # them (measured, profiles/r03/exchange/).
     exchange_form = args.exchange
     if exchange_form == "auto":
         exchange_form = "graph" if (use_dist and args.backend == "nccl") else "sync"

@@ -361,9 +361,9 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                     const bool wide = nn >= 4294967296ll;
                     // hipExtLaunchKernelGGL: with lq_profile_events() set, the events take the kernel's own begin / end timestamps
 #define LQ_FLATR(NT_, GM_) hipExtLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, g_prof_start, g_prof_stop, 0, p, fx, nv, rem)
-                    if (pl.L % 4 == 0) {
+                    if (pl.L % 4 == 0) {                    // (2^32 elements are 16 GiB: `wide` implies `ntb`)
                         if (ntb) { if (wide) LQ_FLATR(1, 2); else LQ_FLATR(1, 0); }
-                        else { if (wide) LQ_FLATR(0, 2); else LQ_FLATR(0, 0); }
+                        else LQ_FLATR(0, 0);
                     } else if (!(off_rb & 512) && (double)pl.L / (double)(pl.nc * pl.CH) >= 0.8) {
                         // long rows with L % 4 != 0 keep the row stream (TAIL instantiation): K1 5.8-6.0 TB/s on rows of 1025,
                         // 2047, 4099, 50177 against 5.4-5.9 for the straddling flat form (development knob 512 selects the latter)
@@ -371,7 +371,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                         return 0;
                     } else {
                         if (ntb) { if (wide) LQ_FLATR(1, 7); else LQ_FLATR(1, 6); }
-                        else { if (wide) LQ_FLATR(0, 7); else LQ_FLATR(0, 6); }
+                        else LQ_FLATR(0, 6);
                     }
 #undef LQ_FLATR
                     return check_hip("flat forward launch") ? -1 : 1;
@@ -435,7 +435,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                 const bool wide = n >= 4294967296ll;
 #define LQ_FLATS(NT_, GM_) hipLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, p, fx, nv, rem)
                 if (nt) { if (wide) LQ_FLATS(1, 7); else LQ_FLATS(1, 6); }
-                else { if (wide) LQ_FLATS(0, 7); else LQ_FLATS(0, 6); }
+                else LQ_FLATS(0, 6);
 #undef LQ_FLATS
                 return check_hip("flat forward launch") ? -1 : 1;
             }
@@ -448,7 +448,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                 const bool wide = n >= 4294967296ll;
 #define LQ_FLATU(NT_, GM_) hipLaunchKernelGGL((k_flat_fwd<OP, 512, NT_, GM_>), dim3((unsigned)blocks), dim3(512), 0, st, p, fx, nv, rem)
                 if (nt) { if (wide) LQ_FLATU(1, 9); else LQ_FLATU(1, 8); }
-                else { if (wide) LQ_FLATU(0, 9); else LQ_FLATU(0, 8); }
+                else LQ_FLATU(0, 8);
 #undef LQ_FLATU
                 return check_hip("flat forward launch") ? -1 : 1;
             }
@@ -477,13 +477,13 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                     if (nt) {
                         if (wide) LQ_FLAT(1, 2); else LQ_FLAT(1, 0);
                     } else {
-                        if (wide) LQ_FLAT(0, 2); else LQ_FLAT(0, 0);
+                        LQ_FLAT(0, 0);
                     }
                 } else {
                     if (nt) {
                         if (wide) LQ_FLAT(1, 5); else LQ_FLAT(1, 4);
                     } else {
-                        if (wide) LQ_FLAT(0, 5); else LQ_FLAT(0, 4);
+                        LQ_FLAT(0, 4);
                     }
                 }
 #undef LQ_FLAT
@@ -492,7 +492,12 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         }
     }
     if (pl.mode == MODE_COL) {
-        constexpr int kUp = (OP == OP_FWD) ? 4 : 2;            // float4 per stream in flight: one stream wants 4, two streams 2
+        // K1 reaches this point only with 2^32 or more elements (every smaller column-mode forward is one of the flat forms
+        // above): the round-1 column kernel serves it -- no pipelined column instantiation exists for the forward
+        if constexpr (OP == OP_FWD) {
+            return 0;
+        } else {
+        constexpr int kUp = 2;                                 // float4 per stream in flight (two streams)
         // K2 of C = 8, 16, 32, 64 as a one-shot stream with FOUR float4 per thread and stream: with two, nothing hid the shuffle
         // tree and the barrier at the end of so short a wave (4.3-5.4 TB/s); with four the epilogue is paid once per 8 KB of each
         // stream: 6.0-6.2 TB/s against 5.5-5.6 for the periodic form.  (K4 with four: 5.6-5.9 against 5.7-6.1 with two.)
@@ -510,7 +515,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                 }
             }
         }
-        if (pl.C <= 64 && pl.per4 && flat_cols_ok(pl.C) && !(off & 64) && OP != OP_BWD) {
+        if constexpr (OP != OP_BWD) if (pl.C <= 64 && pl.per4 && flat_cols_ok(pl.C) && !(off & 64)) {
             // C = 8, 16, 32, 64 as a flat one-shot stream: K1 and K4 (the read-only K2 is faster in the periodic form)
             const int64_t nv = n >> 2;                        // numel = outer * C is a multiple of 8
             constexpr int kU = 2;
@@ -551,8 +556,13 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
 #endif
             // K4 with C >= 16: one float4 per stream in flight (98 VGPRs, 5 waves per SIMD) measured 5.67-5.75 TB/s at C = 64 against
             // 5.30-5.49 with two (128 VGPRs); at C = 3 the other way round (5.57 against 5.24)
-            if (nt && OP == OP_FUSED && pl.C >= 16) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
-            else if (nt) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
+            if constexpr (OP == OP_FUSED) {
+                if (nt && pl.C >= 16) {
+                    hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
+                    return check_hip("periodic column launch") ? -1 : 1;
+                }
+            }
+            if (nt) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)pl.ysplit), dim3(kBlock), 0, st, p, (int)pl.C, pl.ysplit);
             return check_hip("periodic column launch") ? -1 : 1;
         }
@@ -566,9 +576,13 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
             pl.ysplit = nb;               // the finalize that follows must walk the partial layout this launch produces
             pl.np = nb * pl.C;
             pl.n1 = nb;
-            if (nt && OP == OP_FUSED) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
-            else if (nt) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, kUp>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
-            else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
+            if constexpr (OP == OP_FUSED) {
+                if (nt) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
+                else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
+            } else {
+                if (nt) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, kUp>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
+                else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 0, kUp>), dim3((unsigned)nb), dim3(kBlock), 0, st, p, (int)pl.C, nb);
+            }
             return check_hip("periodic column launch") ? -1 : 1;
         }
         // 256 < C <= 512 whose second column block is mostly empty (C = 320: 16 of 64 lanes in half the blocks, K2 / K4 4.7 / 4.5 TB/s)
@@ -580,7 +594,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
                 pl.ysplit = nb;               // the finalize that follows must walk the partial layout this launch produces
                 pl.np = nb * pl.C;
                 pl.n1 = nb;
-                if (OP == OP_FUSED) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1, 512>), dim3((unsigned)nb), dim3(512), 0, st, p, (int)pl.C, nb);
+                if constexpr (OP == OP_FUSED) hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 1, 512>), dim3((unsigned)nb), dim3(512), 0, st, p, (int)pl.C, nb);
                 else hipLaunchKernelGGL((k_col_periodic_pipe<OP, 1, 2, 512>), dim3((unsigned)nb), dim3(512), 0, st, p, (int)pl.C, nb);
                 return check_hip("periodic column launch") ? -1 : 1;
             }
@@ -604,8 +618,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         const int64_t blocks = nbx * pl.ysplit;
         if (blocks > 2147483647ll) return 0;
         LQ_KNOB(pipe_r, "LQ_TUNE_PIPE", 28);      // U*10 + NW (scale-gradient ops)
-        LQ_KNOB(pipe_f, "LQ_TUNE_PIPE_FWD", 28);
-        const int pipe = (OP == OP_FWD) ? pipe_f : pipe_r;
+        const int pipe = pipe_r;
 #define LQ_PIPE(NT_, U_, NW_) hipLaunchKernelGGL((k_col_pipe<OP, NT_, U_, NW_>), dim3((unsigned)blocks), dim3(NW_ * 64), 0, st, p, pl.C, pl.rps, nbx)
         LQ_KNOB(xcd_remap, "LQ_TUNE_XCD", 1);      // development knob: 0 = natural block order for C % 32 != 0
         if (ua) {
@@ -625,6 +638,7 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         }
 #undef LQ_PIPE
         return check_hip("pipelined column launch") ? -1 : 1;
+        }      // OP != OP_FWD
     }
     if constexpr (OP == OP_FWD) {
         return 0;                                      // a forward none of the flat forms above took (e.g. 2^32 or more elements in column mode)
@@ -693,11 +707,13 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
         const int64_t rows_per_block = (int64_t)kWavesPerBlock * (64 >> lg) * U;
         const int64_t blocks = ceil_div(pl.R, rows_per_block);
         if (blocks > 2147483647ll) return 0;
-        const int gm = (p.outer == 1) ? 0 : (pl.R < 4294967296ll ? 1 : 2);
+        // (2^32 or more rows -- 128 GiB per stream at 8 elements a row -- keep the round-1 kernel: a 64-bit row modulo form of
+        // this kernel could not be exercised by any test)
+        if (pl.R >= 4294967296ll) return 0;
+        const int gm = (p.outer == 1) ? 0 : 1;
 #define LQ_TINY3(NT_, U_, LG_) do { \
             if (gm == 0) hipLaunchKernelGGL((k_row_tiny<OP, NT_, U_, LG_, 0>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L); \
-            else if (gm == 1) hipLaunchKernelGGL((k_row_tiny<OP, NT_, U_, LG_, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L); \
-            else hipLaunchKernelGGL((k_row_tiny<OP, NT_, U_, LG_, 2>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L); } while (0)
+            else hipLaunchKernelGGL((k_row_tiny<OP, NT_, U_, LG_, 1>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, pl.R, (int)pl.L); } while (0)
 #ifdef LQ_DEV_KNOBS
 #define LQ_TINY2(NT_) do { \
             if (lg == 1) LQ_TINY3(NT_, 2, 1); \
@@ -718,9 +734,22 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
     }
 }
 
+// The streaming geometry of long rows (512-thread units, nontemporal accesses, two float4 per thread) exists for K1, K2 and K4 --
+// the operations that run on activation-sized tensors.  The penalty terms, the integer view and the element-wise OIHW
+// companion work on weight-sized tensors: they keep the 256-thread units at every size (their entry points plan with
+// make_plan(..., kBlock)), which is a third of the row-stream instantiations and none that a parity test could not reach.
+template <int OP>
+constexpr bool kStreamOp = OP == OP_FWD || OP == OP_BWD || OP == OP_FUSED;
+#ifdef LQ_DEV_KNOBS
+constexpr bool kDevKnobs = true;       // tools/ builds: the LQ_TUNE_* switches can route a descriptor to any form
+#else
+constexpr bool kDevKnobs = false;
+#endif
+
 template <int OP>
 static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
     using O = OpT<OP>;
+    if (!kStreamOp<OP> && pl.mode == MODE_ROW_BIG && pl.bs != kBlock) return fail(LQ_EINVAL, "internal: operation %d planned with %d-thread units", OP, pl.bs);
     {
         const int r2 = launch_stream2<OP>(pl, p, st);
         if (r2 < 0) return LQ_EHIP;
@@ -755,7 +784,7 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         const int64_t outer_f = pl.R / p.G;
         const int grid3d = (p.G <= 65535 && outer_f <= 65535 && pl.R == outer_f * p.G) ? 1 : 0;
         const dim3 grid = grid3d ? dim3((unsigned)pl.nc, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)units);
-        const bool nt = vec && (double)pl.R * (double)pl.L * 4.0 >= (double)kNtBytes;
+        const bool nt = kStreamOp<OP> && vec && (double)pl.R * (double)pl.L * 4.0 >= (double)kNtBytes;
         // Two float4 per thread and stream (see row_stream_body): the backward always (measured 100.3 vs 101.4 us per
         // BENCH step, and 105 vs 116 us at lambda = 1e-3 where every element takes the exact-ratio + tanh branch; it
         // also halves the partials the finalize walks); the fused kernel only when lambda >= 4e-4 (77.4 vs 81.7 us
@@ -770,7 +799,7 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
             const int64_t r = pl.L % CH;
             return pl.L % 4 != 0 || (pl.L > CH && r != 0 && r * 8 <= CH);
         };
-        if (u2) {
+        if constexpr (OP == OP_BWD || OP == OP_FUSED) if (u2) {
             const int64_t nc2 = row_chunks(pl.L, (int64_t)pl.bs * 8);
             const dim3 grid2 = grid3d ? dim3((unsigned)nc2, (unsigned)p.G, (unsigned)outer_f) : dim3((unsigned)(pl.R * nc2));
             if (needs_tail((int64_t)pl.bs * 8))
@@ -789,10 +818,24 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
         // hipExtLaunchKernelGGL with NULL events is a plain launch; with lq_profile_events() set, the events take the kernel's own
         // begin / end timestamps (what rocprofv3 reports as its duration)
         const bool tail1 = needs_tail((int64_t)pl.CH);
+        // (TAIL = 0 forms that no descriptor reaches are not compiled: K1 beyond 256-thread default-policy units, K2 with
+        // nontemporal 512-thread units -- see the two internal errors below)
 #define LQ_LAUNCH_STREAM(VEC_, BS_, NT_) do { \
-        if (VEC_ == 1 || tail1) hipExtLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_, 1, 1>), grid, dim3(BS_), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, pl.nc, grid3d); \
-        else hipExtLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_, 1, 0>), grid, dim3(BS_), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, pl.nc, grid3d); } while (0)
-        if (vec) {
+        constexpr bool kTail0 = kDevKnobs || (VEC_ == 4 && !(OP == OP_FWD && (BS_ != kBlock || NT_ != 0)) && !(OP == OP_BWD && BS_ == 512 && NT_ == 1)); \
+        constexpr bool kTail1 = kDevKnobs || !(OP == OP_BWD && VEC_ == 4 && BS_ == 512 && NT_ == 1); \
+        if (VEC_ == 1 || tail1) { if constexpr (kTail1) hipExtLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_, 1, 1>), grid, dim3(BS_), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, pl.nc, grid3d); } \
+        else { if constexpr (kTail0) hipExtLaunchKernelGGL((k_row_stream<OP, VEC_, BS_, NT_, 1, 0>), grid, dim3(BS_), 0, st, g_prof_start, g_prof_stop, 0, p, pl.L, pl.nc, grid3d); } } while (0)
+        if constexpr (!kStreamOp<OP>) {
+            if (vec) LQ_LAUNCH_STREAM(4, 256, 0);
+            else LQ_LAUNCH_STREAM(1, 256, 0);
+        } else if (!kDevKnobs && OP == OP_FWD && vec && !tail1 && (pl.bs != kBlock || nt)) {
+            // K1 of aligned rows with L % 4 == 0 at streaming size is the flat one-shot stream (launch_stream2): no row-stream
+            // instantiation exists for it
+            return fail(LQ_EINVAL, "internal: streaming-size forward of aligned rows reached the row stream");
+        } else if (!kDevKnobs && OP == OP_BWD && vec && nt && pl.bs == 512) {
+            // K2 with nontemporal 512-thread units always takes two float4 per thread (u2 above)
+            return fail(LQ_EINVAL, "internal: streaming-size scale gradient reached the one-float4 row stream");
+        } else if (vec) {
 #ifdef LQ_DEV_KNOBS
             if (pl.bs == 1024) {
                 if (nt) LQ_LAUNCH_STREAM(4, 1024, 1);
@@ -959,6 +1002,7 @@ int lq_fq_forward(const float* P, const float* s, float* out, void* q, int q_dty
         p.out = out;
         return launch_traverse<OP_FWD>(pl, p, (hipStream_t)stream);
     }
+    pl = make_plan(outer, G, inner, kBlock);      // the integer view alone (callbacks / export): 256-thread units (kStreamOp)
     return launch_traverse<OP_QONLY>(pl, p, (hipStream_t)stream);
 }
 
@@ -980,7 +1024,7 @@ int lq_fq_forward_oihw(const float* P, const float* s, float* out, float* out_oi
     LQ_REQUIRE_PTR(out_oihw);
     if (!out && !(aligned(P, 16) && lq_conv_tile_supported(hw, ci, co, outer, G, inner)))
         return fail(LQ_EINVAL, "lq_fq_forward_oihw: out may be NULL only for kernels the LDS-tile path takes (lq_conv_tile_supported) with P 16-byte aligned");
-    Plan pl = make_plan(outer, G, inner);
+    Plan pl = make_plan(outer, G, inner, kBlock);      // weight-sized operation: 256-thread units at every size (kStreamOp)
     Params p = base_params(P, s, outer, G, inner);
     p.out = out;
     p.out_perm = out_oihw;
@@ -1027,7 +1071,7 @@ int lq_fq_scale_grad_oihw(const float* P, const float* s, const float* dy_oihw, 
     LQ_REQUIRE_PTR(dy_oihw);
     LQ_REQUIRE_PTR(ds);
     LQ_REQUIRE_PTR(dP);
-    Plan pl = make_plan(outer, G, inner);
+    Plan pl = make_plan(outer, G, inner, kBlock);      // weight-sized operation: 256-thread units at every size (kStreamOp)
     Params p = base_params(P, s, outer, G, inner);
     p.dy = P;                     // valid dummy for the traversals' dy loads; the op gathers from dy_perm
     p.dy_perm = dy_oihw;
@@ -1136,7 +1180,7 @@ int lq_penalty_maxbin_fwd(const float* P, const float* s, float* mb, uint32_t* t
     LQ_REQUIRE_PTR(mb);
     LQ_REQUIRE_PTR(ties);
     LQ_REQUIRE_PTR(term);
-    Plan pl = make_plan(outer, G, inner);
+    Plan pl = make_plan(outer, G, inner, kBlock);      // weight-sized operation: 256-thread units at every size (kStreamOp)
     Params p = base_params(P, s, outer, G, inner);
     if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
     if ((rc = launch_traverse<OP_MAXBIN_FWD>(pl, p, (hipStream_t)stream))) return rc;
@@ -1159,7 +1203,7 @@ int lq_penalty_maxbin_bwd(const float* P, const float* s, const float* mb, const
     LQ_REQUIRE_PTR(c_dev);
     LQ_REQUIRE_PTR(dP);
     LQ_REQUIRE_PTR(ds);
-    Plan pl = make_plan(outer, G, inner);
+    Plan pl = make_plan(outer, G, inner, kBlock);      // weight-sized operation: 256-thread units at every size (kStreamOp)
     Params p = base_params(P, s, outer, G, inner);
     p.mb = mb;
     p.ties = ties;
@@ -1178,7 +1222,7 @@ int lq_penalty_difference_fwd(const float* P, const float* s, float* term, void*
     LQ_REQUIRE_PTR(P);
     LQ_REQUIRE_PTR(s);
     LQ_REQUIRE_PTR(term);
-    Plan pl = make_plan(outer, G, inner);
+    Plan pl = make_plan(outer, G, inner, kBlock);      // weight-sized operation: 256-thread units at every size (kStreamOp)
     Params p = base_params(P, s, outer, G, inner);
     if ((rc = bind_ws(p, pl, ws, ws_bytes))) return rc;
     if ((rc = launch_traverse<OP_DIFF_FWD>(pl, p, (hipStream_t)stream))) return rc;
@@ -1196,7 +1240,7 @@ int lq_penalty_difference_bwd(const float* P, const float* s, const float* c_dev
     LQ_REQUIRE_PTR(c_dev);
     LQ_REQUIRE_PTR(dP);
     LQ_REQUIRE_PTR(ds);
-    Plan pl = make_plan(outer, G, inner);
+    Plan pl = make_plan(outer, G, inner, kBlock);      // weight-sized operation: 256-thread units at every size (kStreamOp)
     Params p = base_params(P, s, outer, G, inner);
     p.c_dev = c_dev;
     p.c_scale = c_scale;

@@ -177,7 +177,9 @@ def test_batched_mode_refuses_silent_gradient_accumulation(dev):
 # c-tile is partial) and along co (40, 20, 36, 8, 12), several channel blocks per tile (1x1, 2x2, 1x3), even tap counts;
 # element-wise path: 7x7 and 5x3 (more than 9 taps), co = 10 (co % 4 != 0)
 CONV_SHAPES = [(3, 3, 3, 32), (3, 3, 64, 128), (7, 7, 3, 64), (1, 1, 64, 128), (3, 3, 256, 256), (1, 1, 512, 2048), (5, 3, 6, 10),
-               (3, 3, 48, 40), (2, 2, 100, 20), (1, 3, 33, 36), (3, 1, 16, 8), (1, 1, 300, 12), (3, 3, 160, 96)]
+               (3, 3, 48, 40), (2, 2, 100, 20), (1, 3, 33, 36), (3, 1, 16, 8), (1, 1, 300, 12), (3, 3, 160, 96),
+               # two-stage K2 (lq_conv_tile.hpp): odd numbers of channel blocks, partial stages, two taps, one channel in the last wave
+               (1, 1, 96, 64), (1, 1, 160, 32), (1, 2, 70, 16), (1, 1, 40, 8), (3, 3, 5, 4), (2, 3, 29, 68), (1, 1, 2048, 64)]
 
 
 @pytest.mark.parametrize("orient", ["rowwise", "columnwise", "channelwise", "scalar"])

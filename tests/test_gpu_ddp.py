@@ -158,6 +158,22 @@ def test_nqcl_unbatched_mode_b_is_refused():
         dist.destroy_process_group()
 
 
+def test_bench_exchange_captured_in_the_step_graph_costs_a_few_percent():
+    """bench.py --force-dist (default exchange: the RCCL all-reduce captured in the chain of the step graph) against bench.py
+    --graph (the same graphs without any collective), one-rank communicator: 2.5 % measured (profiles/r03/exchange/); the
+    eager sync exchange costs 10 %.  Bound at 5 % to stay clear of box-to-box noise."""
+    import json
+    common = ["--steps", "160", "--warmup", "32", "--no-cpu-baseline", "--no-extras"]
+    def run(extra):
+        out = _run_script([os.path.join(ROOT, "bench.py")] + extra + common)
+        return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    plain = run(["--graph"])
+    captured = run(["--force-dist"])
+    assert "hipGraph" in captured["config"]["launch"] and "captured" in captured["config"]["exchange"], captured["config"]
+    ratio = captured["ms_per_step"] / plain["ms_per_step"]
+    assert ratio < 1.05, (ratio, captured["ms_per_step"], plain["ms_per_step"])
+
+
 @pytest.mark.parametrize("mode,loss", [("nqcl", "maxbin"), ("cl", "difference")])
 def test_one_rank_rccl_penalty_injection_on_bucket_views(mode, loss):
     """The batched penalty kernels write straight into the data-parallel bucket's gradient views: every view must satisfy the

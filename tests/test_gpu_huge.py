@@ -138,3 +138,54 @@ def test_flat_forward_beyond_2_to_32_elements(L):
         for got, name in ((ds, "split"), (ds2, "fused")):
             torch.testing.assert_close(got[a:b].reshape(-1), ref, rtol=2e-5, atol=1e-30, msg=lambda m_: f"{name} ds rows {a}..{b}: {m_}")
         del qr, outr, nz, ratio, m, vote
+
+
+@pytest.mark.parametrize("C", [4, 68, 65])
+def test_column_forward_and_statistics_beyond_2_to_32_elements(C):
+    """More than 2^32 elements in column mode (`inner == 1`, per-column scales: NHWC per-channel activations): the flat forward
+    with 64-bit group arithmetic -- C = 4 / 68: the four scales of a float4 are one aligned float4 of the scale vector (k_flat_fwd
+    group mode 5); C = 65: the same, dword-aligned, wrapping around the row end (mode 9) -- and the 64-bit index forms of the
+    tracking statistics (custom_callbacks.py:85-99: unique integers and max|q| over an axis).  Reference: the same three fp32
+    operations in torch on the device, chunked; the oracle on rows across the 2^32 boundary."""
+    import learned_quantization_amd as lq
+    dev = torch.device("cuda:0")
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
+        pytest.skip("needs ~40 GB of device memory")
+    R = (2 ** 32) // C + 1001
+    assert R * C > 2 ** 32
+    g = torch.Generator(device=dev).manual_seed(4 + C)
+    P = torch.empty(R, C, device=dev)
+    rows = (1 << 28) // C
+    for a in range(0, R, rows):
+        b = min(R, a + rows)
+        P[a:b] = torch.randn(b - a, C, device=dev, generator=g) * 0.05
+    s = torch.rand(1, C, device=dev, generator=g) * 9e-3 + 1e-3
+    out = lq.fq_forward(P, s)
+    qmax = torch.zeros(C, device=dev)
+    qlo, qhi = 0.0, 0.0
+    for a in range(0, R, rows):
+        b = min(R, a + rows)
+        qr = torch.floor(P[a:b] / s)
+        assert torch.equal(out[a:b], qr * s), f"rows {a}..{b}"
+        qmax = torch.maximum(qmax, qr.abs().amax(0))
+        qlo, qhi = min(qlo, float(qr.min())), max(qhi, float(qr.max()))
+        del qr
+    a = (2 ** 32) // C - 2
+    _, out_o = O.fq_forward(P[a:a + 4].cpu().numpy(), s.cpu().numpy())
+    np.testing.assert_array_equal(out[a:a + 4].cpu().numpy(), out_o)
+    del out
+    if C != 4:
+        return
+    # statistics with 64-bit element indices: max|q| over axis 0 (per column), and the unique integers with their counts
+    got = lq.q_absmax_over_axis(P, s, 0)
+    assert torch.equal(got.reshape(-1), qmax)
+    values, counts = lq.q_unique(P, s)
+    assert int(counts.sum()) == R * C
+    assert float(values.min()) == qlo and float(values.max()) == qhi
+    # the count of one integer against torch, chunked
+    v0 = int(values[len(values) // 2])
+    n0 = 0
+    for a in range(0, R, rows):
+        b = min(R, a + rows)
+        n0 += int((torch.floor(P[a:b] / s) == v0).sum())
+    assert int(counts[len(values) // 2]) == n0
