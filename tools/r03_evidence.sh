@@ -27,6 +27,19 @@ base_r02)
       done
       python3 $GRAFT_REPO_ROOT/tools/prof_batch_summary.py $d $only > $d/summary.txt; cat $d/summary.txt
     done ) || exit 1 ;;
+base_r02_oihw)
+  ( cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT/_base_r02
+    for only in imagenette:channelwise resnet50:channelwise; do
+      d=$GRAFT_REPO_ROOT/$out/base_r02_oihw_$(echo $only | tr ':' '_'); mkdir -p $d
+      timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 ../tools/base_r02_oihw.py $only > $d/run.log 2> $d/err.log || { tail -n 5 $d/err.log; exit 1; }
+      cat $d/run.log
+      python3 - "$(ls -S $d/*/*_kernel_stats.csv | head -n 1)" <<'PY'
+import csv,sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if "k_batch_traverse" in r["Name"]:
+        print(f'  {r["Name"].split("(")[0].replace("void ","")[:40]:40s} calls={r["Calls"]:>5s} avg={float(r["AverageNs"])/1e3:7.2f} min={float(r["MinNs"])/1e3:7.2f}')
+PY
+    done ) || exit 1 ;;
 sweeps)
   timeout -k 10 600 python3 tools/bench_weights.py > $out/r03_weight_sweeps.jsonl 2> $out/sweeps.err || exit 1
   cat $out/r03_weight_sweeps.jsonl ;;
@@ -84,6 +97,26 @@ quick)
 newtests)
   timeout -k 10 900 python3 -m pytest tests/test_gpu_ddp.py tests/test_gpu_layers.py -q -m gpu -x -p no:cacheprovider > $out/pytest_new.log 2>&1; rc=$?
   tail -n 15 $out/pytest_new.log; [ $rc -eq 0 ] || exit 1 ;;
+pmc)
+  # HBM traffic of K1 / K2 / K4 on the BENCH tensor (FETCH_SIZE / WRITE_SIZE passes) -> traffic.json tied to the kernel sources
+  bash tools/prof_pmc.sh $out/pmc || exit 1
+  cat $out/pmc/traffic.json | head -n 5 ;;
+stats)
+  # rocprofv3 --kernel-trace --stats of exactly the default bench command
+  cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+  mkdir -p $out/default_cmd
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/default_cmd -- python3 bench.py > $out/default_cmd/bench.json 2> $out/default_cmd/err.log || exit 1
+  python3 - "$(find $out/default_cmd -name '*kernel_stats.csv' | head -n 1)" <<'PY'
+import csv,sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if "lq::" in r["Name"]:
+        print(f'{r["Name"][:74]:74s} calls={r["Calls"]:>5s} avg_us={float(r["AverageNs"])/1e3:8.2f}')
+PY
+  ;;
+membench)
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/membench tools/membench.hip || exit 1
+  timeout -k 10 300 /tmp/membench > $out/membench.txt 2>&1 || exit 1
+  grep "BS512" $out/membench.txt | head -n 12 ;;
 bench)
   timeout -k 10 400 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err || exit 1
   cat $out/bench_default.json ;;
