@@ -2,9 +2,9 @@
 //
 // The reference keeps conv kernels in HWIO (custom_layers.py:321) and MIOpen consumes OIHW.  Round 2 emitted the OIHW
 // companion of K1 (and gathered K2's upstream gradient) element by element: 4-byte accesses 4*ci*hw bytes apart.
-// rocprofv3 on the ResNet-18-like weight set (profiles/r03/baseline_*): forward 64.8 us with 183 MB written for 89 MB of
-// output (every 128-byte line of the companion reaches memory in pieces), gathered backward 58.7 us -- 2.5-3x the plain
-// traversals.  Here a block owns a TILE
+// rocprofv3 on the ResNet-18-like weight set with the round-2 sources (profiles/r03/base_r02_*, base_r02_oihw_*): forward
+// 66.6 us with 184.6 MB written for 89.4 MB of output (every 128-byte line of the companion reaches memory in pieces),
+// gathered backward 59.8 us -- 2.5-3x the plain traversals.  Here a block owns a TILE
 //
 //      c in [c0, c0 + 32 m)   x   o in [o0, o0 + 32)   x   every h = (kh, kw)            32 m hw <= 288 elements per o
 //
@@ -28,6 +28,14 @@
 //   kind 1   rowwise / columnwise / scalar: g = (h / A) % G -- uniform over the block; the passes are visited group by group
 //            and each wave leaves one partial per (group, tile, wave).
 // Vote sums are exact (lq_common.hpp, Acc), so ds does not depend on this choice of partials: bit-identical to lq_fq_scale_grad.
+//
+// Measured with these tiles (profiles/r03/batch_*, quick*): forward 23.3 us (20.0 us without the optional HWIO output), OIHW
+// scale gradient 32.4 us.  K2 holds 37 KB of LDS and 113 VGPRs per block -- four blocks per CU, 1024 of the set's 1250 tiles at a
+// time; the 226 others start as the first finish and cost 10 of the 32 us (profiles/r03/timelines/).  Two attempts at that tail
+// were measured and dropped, patches and numbers kept under profiles/r03/experiments/: the tile through LDS in two halves (five
+// blocks per CU, every tile resident: 33-34 us -- each wave then pays two dependent gradient round trips) and half-size tiles for
+// the tasks that start last (34 us -- a half-size block lives as long as a full one).  The kernel is bound by a wave's latency
+// chain, not by residency.
 #ifndef LQ_CONV_TILE_HPP_
 #define LQ_CONV_TILE_HPP_
 #include "lq_stream2.hpp"

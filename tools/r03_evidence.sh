@@ -117,6 +117,32 @@ membench)
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/membench tools/membench.hip || exit 1
   timeout -k 10 300 /tmp/membench > $out/membench.txt 2>&1 || exit 1
   grep "BS512" $out/membench.txt | head -n 12 ;;
+e2e)
+  # end-to-end steps of the BASELINE configs (synthetic data), as profiles/r02_e2e.jsonl: eager / batched / graphed, the one-rank
+  # RCCL group (the one-graph step with the captured all-reduce is the default graphed data-parallel form since round 3), mode B,
+  # nested quantization + loss term, the ResNets at the per-GPU batch sizes of BASELINE.json
+  rm -f $out/r03_e2e.jsonl
+  run() { timeout -k 10 600 python3 -m learned_quantization_amd.train "$@" 2>> $out/e2e.err | grep '^{' >> $out/r03_e2e.jsonl || { tail -n 5 $out/e2e.err; exit 1; }; }
+  for args in "" "--batched" "--batched --graph" "--force-dist --batched" "--force-dist --batched --graph --no-graph-collectives" "--force-dist --batched --graph" "--force-dist --batched --graph --ddp-mode B"; do
+    run --config cifar --batch 256 --steps 60 --warmup 15 $args
+  done
+  run --config cifar --mode nqcl --loss maxbin --value 1e-11 --rate 1e-7 --batch 256 --steps 60 --warmup 15 --batched --graph
+  run --config cifar --mode nqcl --loss maxbin --value 1e-11 --rate 1e-7 --batch 128 --steps 60 --warmup 15 --batched --graph --force-dist
+  run --config cifar --mode nqcl --loss maxbin --value 1e-11 --rate 1e-7 --batch 128 --steps 60 --warmup 15 --batched --graph --force-dist --ddp-mode B
+  run --config imagenette --batch 64 --steps 12 --warmup 4 --batched --graph
+  run --config imagenette --batch 256 --steps 8 --warmup 3 --batched --graph
+  run --config imagenette --batch 256 --steps 8 --warmup 3 --batched --graph --force-dist --ddp-mode B
+  run --config resnet50 --value 1e-11 --value-coarse 1e-10 --batch 32 --steps 12 --warmup 4 --batched --graph
+  run --config resnet50 --value 1e-11 --value-coarse 1e-10 --batch 256 --steps 6 --warmup 3 --batched --graph --force-dist
+  python3 - $out/r03_e2e.jsonl <<'PY'
+import sys,json
+for l in open(sys.argv[1]):
+    d=json.loads(l); print(d.get('config'), d.get('mode'), d.get('per_gpu_batch'), 'graph' if d.get('hipgraph') else 'eager', 'one-graph' if d.get('graph_collectives') else '', 'batched' if d.get('batched') else '', d.get('backend'), d.get('ddp_mode'), round(d['value']), 'img/s', round(d['ms_per_step'],3), 'ms')
+PY
+  ;;
+sweeps_companion)
+  timeout -k 10 300 python3 tools/bench_weights.py --abi-only --companion-only > $out/r03_weight_sweeps_companion_only.jsonl 2>> $out/sweeps.err || exit 1
+  cat $out/r03_weight_sweeps_companion_only.jsonl ;;
 bench)
   timeout -k 10 400 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err || exit 1
   cat $out/bench_default.json ;;
