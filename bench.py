@@ -304,6 +304,12 @@ def main():
     if want_graph:
         S = max(1, args.graph_steps)
         try:
+            if use_dist:
+                # two eager steps first: RCCL sets up its channels, buffers and kernels at the first collective of a communicator
+                # (allocations and IPC exchanges that must not happen inside a capture)
+                for i in range(2):
+                    step(i)
+                fence()
             torch.cuda.synchronize(dev)
             graphs = {S: capture(S)}
             for r in {args.warmup % S, args.steps % S} - {0}:
@@ -511,10 +517,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": kbytes, "avg_launch_us": kt * 1e6, **extra,
-                         # math-free kernels of the same shape on this device class (profiles/r01_membench.txt): what a
-                         # streaming kernel can reach of the 8 TB/s spec peak
-                         "stream_ceiling_GBs": {"read1_write1": 6579, "read2": 6808, "read2_write1": 6507,
-                                                "source": "profiles/r01_membench.txt"}},
+                         # math-free kernels of the same shape on this device class (tools/membench, re-measured in round 3:
+                         # 512 threads, nontemporal): what a streaming kernel can reach of the 8 TB/s spec peak.  Box to box the
+                         # figures move by 2-3 % (round 1: 6579 / 6808 / 6507)
+                         "stream_ceiling_GBs": {"read1_write1": 6637, "read2": 6689, "read2_write1": 6385,
+                                                "source": "profiles/r03/membench.txt"}},
         }
         if world == 1 and not args.no_extras and graphs is None:
             line["extras"] = extras
