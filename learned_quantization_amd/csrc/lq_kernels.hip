@@ -320,6 +320,12 @@ static void col_variant(const Plan& pl, const void* P, const void* dy, const voi
 // development knobs of the streaming forms: LQ_TUNE_S2 = bit mask of forms to DISABLE (1 flat K1, 2 pipelined column tile,
 // 4 pipelined periodic columns, 8 tiny-row passes, ...); LQ_TUNE_PIPE = U*10 + NW of the column tile; LQ_TUNE_TINY_U = passes
 
+#ifdef LQ_DEV_KNOBS
+constexpr bool kDevKnobs = true;       // tools/ builds: the LQ_TUNE_* switches can route a descriptor to any form
+#else
+constexpr bool kDevKnobs = false;
+#endif
+
 // Streaming-size (>= 4 M elements) forms of lq_stream2.hpp.  Returns 1 when it launched the traversal, 0 when the
 // round-1 traversal should run, < 0 on error.
 template <int OP>
@@ -673,26 +679,75 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
             const int nwin = (int)(pl.L % 4 ? (pl.L + 3 + 3) / 4 : pl.L / 4);     // float4s of the widest window of a row
             int lg = 1;
             while ((1 << lg) < nwin && lg < 6) ++lg;
-            const int V = lg == 6 ? (nwin + 63) / 64 : 1;
+            int V = lg == 6 ? (nwin + 63) / 64 : 1;
+            // Round 3: rows of 65..340 elements.  The smallest power-of-two team with one float4 per lane leaves half the lanes
+            // idle just above a power of two (rows of 68: 17 of 32 lanes) -- and, what costs more, pays the per-row work (context,
+            // team reduction, emit) once per 32 or 64 lanes.  Teams of 16 / 32 lanes with 2-3 float4 per lane put two to four times
+            // as many rows into a wave at 256- / 512-byte pieces per team and load.  Measured on 33.5 M elements, outer == 1
+            // (tools/r03_win_geom.sh, profiles/r03/short_rows/): K2 rows of 68: 4.0 -> 5.0 TB/s, 88: 5.0 -> 6.0, 131: 3.7 -> 5.7,
+            // 160: 4.9 -> 6.3, 260: 5.4 -> 6.1; K4 keeps the wider team where its stores want it (rows of 84..124 unless they are
+            // whole 64-byte multiples): 68: 4.5 -> 4.9, 132: 4.5 -> 5.0, 160: 5.2 -> 6.0, 200: 5.5 -> 5.8.  (Teams of 8 lanes --
+            // 128-byte pieces -- and two rows per team next to several float4 per lane both measured worse.)
+            if constexpr (OP == OP_BWD) {
+                if (nwin >= 17 && nwin <= 32) { lg = 4; V = 2; }
+                else if (nwin >= 33 && nwin <= 48) { lg = 4; V = 3; }
+                else if (nwin >= 49 && nwin <= 55) { lg = 5; V = 2; }
+                else if (nwin >= 65 && nwin <= 84) { lg = 5; V = 3; }
+            } else {
+                if (nwin >= 17 && nwin <= 32 && (nwin <= 19 || pl.L % 16 == 0)) { lg = 4; V = 2; }
+                else if (nwin >= 33 && nwin <= 64) { lg = 5; V = 2; }
+            }
             const int U = V == 1 ? 2 : 1;
             const int64_t rows_per_block = (int64_t)kWavesPerBlock * (64 >> lg) * U;
             const int64_t blocks = ceil_div(pl.R, rows_per_block);
             if (blocks <= 2147483647ll && V <= 5) {
                 const FastDiv fG = make_fastdiv((uint32_t)p.G);
 #define LQ_WIN(NT_, LG_, V_, U_) hipLaunchKernelGGL((k_row_win<OP, NT_, LG_, V_, U_>), dim3((unsigned)blocks), dim3(kBlock), 0, st, p, fG, pl.R, (int)pl.L, n)
+                // (only the combinations the rules above can produce are compiled: K2 never runs 32 lanes x 1, K4 never 64 x 1)
 #define LQ_WIN2(NT_) do { \
                 switch (lg * 8 + V) { \
                     case 1 * 8 + 1: LQ_WIN(NT_, 1, 1, 2); break; \
                     case 2 * 8 + 1: LQ_WIN(NT_, 2, 1, 2); break; \
                     case 3 * 8 + 1: LQ_WIN(NT_, 3, 1, 2); break; \
                     case 4 * 8 + 1: LQ_WIN(NT_, 4, 1, 2); break; \
-                    case 5 * 8 + 1: LQ_WIN(NT_, 5, 1, 2); break; \
-                    case 6 * 8 + 1: LQ_WIN(NT_, 6, 1, 2); break; \
+                    case 4 * 8 + 2: LQ_WIN(NT_, 4, 2, 1); break; \
+                    case 4 * 8 + 3: if constexpr (OP == OP_BWD || kDevKnobs) LQ_WIN(NT_, 4, 3, 1); break; \
+                    case 5 * 8 + 1: if constexpr (OP != OP_BWD || kDevKnobs) LQ_WIN(NT_, 5, 1, 2); break; \
+                    case 5 * 8 + 2: LQ_WIN(NT_, 5, 2, 1); break; \
+                    case 5 * 8 + 3: if constexpr (OP == OP_BWD || kDevKnobs) LQ_WIN(NT_, 5, 3, 1); break; \
+                    case 6 * 8 + 1: if constexpr (OP == OP_BWD || kDevKnobs) LQ_WIN(NT_, 6, 1, 2); break; \
                     case 6 * 8 + 2: LQ_WIN(NT_, 6, 2, 1); break; \
                     case 6 * 8 + 3: LQ_WIN(NT_, 6, 3, 1); break; \
                     case 6 * 8 + 4: LQ_WIN(NT_, 6, 4, 1); break; \
                     default: LQ_WIN(NT_, 6, 5, 1); break; \
                 } } while (0)
+#ifdef LQ_DEV_KNOBS
+                // development: LQ_TUNE_WIN_GEOM = LG * 100 + V * 10 + U forces the team geometry (teams of 2^LG lanes, V float4 per lane,
+                // U rows per team and wave)
+                LQ_KNOB(geom, "LQ_TUNE_WIN_GEOM", 0);
+                if (geom >= 100 && nt && ((geom / 10) % 10) * (1 << (geom / 100)) >= nwin) {
+                    const int glg = geom / 100, gu = geom % 10;
+                    const int64_t gblocks = ceil_div(pl.R, (int64_t)kWavesPerBlock * (64 >> glg) * gu);
+                    bool done = true;
+#define LQ_WING(LG_, V_, U_) hipLaunchKernelGGL((k_row_win<OP, 1, LG_, V_, U_>), dim3((unsigned)gblocks), dim3(kBlock), 0, st, p, fG, pl.R, (int)pl.L, n)
+                    switch (geom) {
+                        case 421: LQ_WING(4, 2, 1); break;
+                        case 422: LQ_WING(4, 2, 2); break;
+                        case 431: LQ_WING(4, 3, 1); break;
+                        case 432: LQ_WING(4, 3, 2); break;
+                        case 521: LQ_WING(5, 2, 1); break;
+                        case 522: LQ_WING(5, 2, 2); break;
+                        case 531: LQ_WING(5, 3, 1); break;
+                        case 532: LQ_WING(5, 3, 2); break;
+                        case 541: LQ_WING(5, 4, 1); break;
+                        case 414: LQ_WING(4, 1, 4); break;
+                        case 514: LQ_WING(5, 1, 4); break;
+                        default: done = false;
+                    }
+#undef LQ_WING
+                    if (done) return check_hip("row-window launch") ? -1 : 1;
+                }
+#endif
                 if (nt) LQ_WIN2(1); else LQ_WIN2(0);
 #undef LQ_WIN2
 #undef LQ_WIN
@@ -740,11 +795,6 @@ static int launch_stream2_impl(Plan& pl, const Params& p, hipStream_t st) {
 // make_plan(..., kBlock)), which is a third of the row-stream instantiations and none that a parity test could not reach.
 template <int OP>
 constexpr bool kStreamOp = OP == OP_FWD || OP == OP_BWD || OP == OP_FUSED;
-#ifdef LQ_DEV_KNOBS
-constexpr bool kDevKnobs = true;       // tools/ builds: the LQ_TUNE_* switches can route a descriptor to any form
-#else
-constexpr bool kDevKnobs = false;
-#endif
 
 template <int OP>
 static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {

@@ -59,6 +59,17 @@ CASES = [
     ((420001, 10), "rowwise", 1e-10, "row windows LG 2, default policy"),
     ((162001, 26), "rowwise", 3e-2, "row windows LG 3, default policy"),
     ((34501, 122), "rowwise", 1e-10, "row windows LG 5, default policy"),
+    # round 3: teams of 16 / 32 lanes with two or three float4 per lane for rows of 65..340 elements (K2 and K4 choose differently)
+    ((_rows(NT, 68) + 1, 68), "rowwise", 1e-10, "rows of 68, nt: 16 lanes x 2 (K2 and K4)"),
+    ((_rows(NT, 100) + 1, 100), "rowwise", 3e-2, "rows of 100, nt: K2 16 lanes x 2, K4 32 lanes x 1"),
+    ((2, _rows(NT, 2 * 132) + 1, 132), "columnwise", 1e-10, "rows of 132, nt, outer > 1: K2 16 lanes x 3, K4 32 lanes x 2"),
+    ((_rows(NT, 200) + 1, 200), "rowwise", 3e-2, "rows of 200, nt: 32 lanes x 2 (K2 and K4)"),
+    ((_rows(NT, 300) + 1, 300), "rowwise", 1e-10, "rows of 300, nt: K2 32 lanes x 3, K4 64 lanes x 2"),
+    ((62001, 68), "rowwise", 3e-2, "rows of 68, default policy: 16 lanes x 2"),
+    ((42101, 100), "rowwise", 1e-10, "rows of 100, default policy: K2 16 lanes x 2"),
+    ((32001, 131), "rowwise", 3e-2, "rows of 131 (off the grid), default policy: K2 16 lanes x 3, K4 32 lanes x 2"),
+    ((2, 10551, 200), "columnwise", 1e-10, "rows of 200, default policy, outer > 1: 32 lanes x 2"),
+    ((14101, 300), "rowwise", 3e-2, "rows of 300, default policy: K2 32 lanes x 3"),
     # rows of 1153..1945 elements as one wave per row (two 1024-chunks otherwise): 5..8 float4 per lane
     ((_rows(NT, 1200) + 1, 1200), "rowwise", 1e-10, "one wave per row, 5 float4 per lane, nt"),
     ((_rows(NT, 1500) + 1, 1500), "rowwise", 3e-2, "one wave per row, 6 float4 per lane, nt"),
