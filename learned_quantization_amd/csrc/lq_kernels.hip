@@ -1004,6 +1004,12 @@ int lq_dev_set_ablate(int mask) {      // development builds only (see lq_conv_t
 #endif
 
 #ifdef LQ_DEV_KNOBS
+int lq_dev_set_flags(int bits) {       // development builds only (see lq_stream2.hpp)
+    return hipMemcpyToSymbol(HIP_SYMBOL(lq::g_dev_flags), &bits, sizeof(int)) == hipSuccess ? LQ_OK : LQ_EHIP;
+}
+#endif
+
+#ifdef LQ_DEV_KNOBS
 int lq_dev_set_trace(void* buf) {      // development builds only: block timeline of the batch traversals (lq_conv_tile.hpp)
     unsigned long long* b = (unsigned long long*)buf;
     return hipMemcpyToSymbol(HIP_SYMBOL(lq::g_trace), &b, sizeof(b)) == hipSuccess ? LQ_OK : LQ_EHIP;

@@ -48,6 +48,11 @@ namespace lq {
 //            the row-stream kernel would start every block in the middle of a 128-byte line (each 1 KB wave access then touches
 //            9 lines instead of 8: K1 5.4-5.9 TB/s); as a flat stream every access is line-aligned, a float4 has one group
 //            unless it straddles a row end -- checked from the groups of its first and last element (32-bit / 64-bit)
+#ifdef LQ_DEV_KNOBS
+// development builds: lq_dev_set_flags(bits) -- 1: k_row_win stores with the default cache policy (loads stay nontemporal)
+__device__ int g_dev_flags = 0;
+#endif
+
 template <bool WIDE>
 __device__ __forceinline__ int64_t flat_group_w(const Params& p, const FlatIdx& fx, int64_t i) {
     if (WIDE) return (i / p.inner) % p.G;
@@ -702,6 +707,10 @@ __global__ __launch_bounds__(kBlock) void k_row_win(Params p, FastDiv fG, int64_
                     const float4 r = apply4<O>(p, ctx, i0, xx, dd, acc[u]);
                     if (O::kStore) {
                         if (__builtin_expect(full, 1)) {
+#ifdef LQ_DEV_KNOBS
+                            if (g_dev_flags & 1) store4<0>(p.out + i0, r);
+                            else
+#endif
                             store4<NT>(p.out + i0, r);
                         } else {                              // neighbouring rows own the other elements of this float4
                             if (off + 0 >= 0 && off + 0 < L) p.out[i0 + 0] = r.x;

@@ -28,6 +28,11 @@ dev = torch.device("cuda:0")
 outer, G, inner = args.outer, args.G, args.inner
 n = outer * G * inner
 lib = lq._hip.load()
+if os.environ.get("LQ_DEV_FLAGS"):          # development library only: lq_dev_set_flags (lq_stream2.hpp)
+    import ctypes
+    lib.lq_dev_set_flags.restype = ctypes.c_int
+    lib.lq_dev_set_flags.argtypes = [ctypes.c_int]
+    assert lib.lq_dev_set_flags(int(os.environ["LQ_DEV_FLAGS"])) == 0
 sets = []
 for k in range(args.sets):
     P = torch.rand(n, device=dev) * 200 - 100
