@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: tools/r03_evidence.sh <outdir> <step>...   (GPU box, repo root) -- round-3 evidence, one step per word:
+# usage: tools/r03_evidence.sh <outdir> <step>...   (GPU box, repo root) -- round-3 evidence, one step per word
+# (base_r02*: first `mkdir _base_r02 && git archive ad7e194 | tar -x -C _base_r02 && make -C _base_r02/learned_quantization_amd/csrc`):
 #   tests      the GPU parity suite (plain)
 #   batch      rocprofv3 stats + FETCH/WRITE/SQ counters of the multi-tensor batch on the ResNet-18-like / ResNet-50-like sets
 #   base_r02   the same kernel stats + FETCH/WRITE of the round-2 sources (tree at ad7e194 extracted to _base_r02/, built there)
