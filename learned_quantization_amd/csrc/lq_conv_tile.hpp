@@ -30,7 +30,7 @@
 // Vote sums are exact (lq_common.hpp, Acc), so ds does not depend on this choice of partials: bit-identical to lq_fq_scale_grad.
 //
 // Measured with these tiles (profiles/r03/batch_*, quick*): forward 23.3 us (20.0 us without the optional HWIO output), OIHW
-// scale gradient 32.4 us.  K2 holds 37 KB of LDS and 113 VGPRs per block -- four blocks per CU, 1024 of the set's 1250 tiles at a
+// scale gradient 32.4 us (30.1 us since the run-order offsets are carried from access to access, profiles/r03/experiments/ring/).  K2 holds 37 KB of LDS and 113 VGPRs per block -- four blocks per CU, 1024 of the set's 1250 tiles at a
 // time; the 226 others start as the first finish and cost 10 of the 32 us (profiles/r03/timelines/).  Two attempts at that tail
 // were measured and dropped, patches and numbers kept under profiles/r03/experiments/: the tile through LDS in two halves (five
 // blocks per CU, every tile resident: 33-34 us -- each wave then pays two dependent gradient round trips) and half-size tiles for
@@ -117,6 +117,27 @@ __device__ __forceinline__ CtGeom ct_geom(const ConvTile& ct, uint32_t b) {
     return g;
 }
 
+// Run-order walk of a wave's slice, e = lane + 64 i -> (o_l, k) = divmod(e, RLw): the starting offsets of a lane and what one
+// step of 64 elements adds to the byte offset in an OIHW tensor (row stride `ostride` floats) and in the wave's LDS slice
+// (row stride kCtStrideW words), without / with a wrap of k.
+struct CtStep {
+    uint32_t sr, k0, g0, l0, ginc0, ginc1, linc0, linc1;
+};
+__device__ __forceinline__ CtStep ct_step(const CtGeom& g, uint32_t ostride) {
+    CtStep s;
+    const uint32_t sq = (64u * g.M) >> 20;                         // 64 / RLw (exact: see ct_geom)
+    s.sr = 64u - sq * g.RLw;                                       // 64 % RLw
+    const uint32_t o0 = (g.lane * g.M) >> 20;
+    s.k0 = g.lane - o0 * g.RLw;
+    s.g0 = (o0 * ostride + s.k0) * 4u;
+    s.l0 = (o0 * (uint32_t)kCtStrideW + s.k0) * 4u;
+    s.ginc0 = (sq * ostride + s.sr) * 4u;
+    s.ginc1 = s.ginc0 + (ostride - g.RLw) * 4u;
+    s.linc0 = (sq * (uint32_t)kCtStrideW + s.sr) * 4u;
+    s.linc1 = s.linc0 + ((uint32_t)kCtStrideW - g.RLw) * 4u;
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------
 //  K1 on a tile: out (HWIO) from registers, out_perm (OIHW) through the wave's LDS slice when p.out_perm is set.
 //  No block barrier: a wave transposes its own 8 m channels (LDS executes a wave's accesses in order), kCtFwdStage output
@@ -165,6 +186,7 @@ __device__ __forceinline__ void conv_tile_fwd(const Params& p, const ConvTile& c
         float* lw = lds + g.w * (kCtFwdStage * kCtStrideW);
         float* dst = p.out_perm + ((size_t)g.o0 * ct.ci + g.c0 + g.wc0) * ct.hw;
         const uint32_t ostride = ct.ci * ct.hw;
+        const CtStep st = ct_step(g, ostride);                  // carried offsets of the run-order walk (see conv_tile_bwd)
 #pragma unroll 1
         for (uint32_t r = 0; r < (uint32_t)(kCtO / kCtFwdStage); ++r) {
             if (r * kCtFwdStage >= g.to_eff) break;             // block-uniform
@@ -184,12 +206,19 @@ __device__ __forceinline__ void conv_tile_fwd(const Params& p, const ConvTile& c
             __builtin_amdgcn_wave_barrier();
             const uint32_t no = g.to_eff - r * kCtFwdStage < (uint32_t)kCtFwdStage ? g.to_eff - r * kCtFwdStage : (uint32_t)kCtFwdStage;
             const uint32_t E = no * g.RLw;
+            {
+                uint32_t k = st.k0, goff = st.g0 + r * (uint32_t)kCtFwdStage * ostride * 4u, loff = st.l0;
+                char* dstb = reinterpret_cast<char*>(dst);
+                const char* lwb = reinterpret_cast<const char*>(lw);
 #pragma unroll
-            for (int i = 0; i < kCtFwdStage * kCtRunW / 64; ++i) {
-                const uint32_t e = g.lane + 64u * (uint32_t)i;
-                if (e < E) {
-                    const uint32_t o_l = (e * g.M) >> 20, k = e - o_l * g.RLw;
-                    dst[(r * kCtFwdStage + o_l) * ostride + k] = lw[o_l * kCtStrideW + k];
+                for (int i = 0; i < kCtFwdStage * kCtRunW / 64; ++i) {
+                    const uint32_t e = g.lane + 64u * (uint32_t)i;
+                    if (e < E) *reinterpret_cast<float*>(dstb + goff) = *reinterpret_cast<const float*>(lwb + loff);
+                    k += st.sr;
+                    const bool wrap = k >= g.RLw;
+                    k -= wrap ? g.RLw : 0u;
+                    goff += wrap ? st.ginc1 : st.ginc0;
+                    loff += wrap ? st.linc1 : st.linc0;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -222,7 +251,7 @@ __device__ __forceinline__ void ct_flush(const Params& p, const ConvTile& ct, co
 // three waves per SIMD -- showed every block alive for the whole launch; with two passes in flight a block that starts late
 // (the second round of a launch with more tiles than the chip holds) needed nine dependent memory round trips: 15 us alone
 // on an idle chip.
-constexpr int kCtAhead = 4;
+constexpr int kCtAhead = 4;      // (six and nine passes ahead, with the registers the carried offsets freed: 31.9 / 33.3 us against 30.1)
 
 __device__ __forceinline__ void conv_tile_bwd(const Params& p, const ConvTile& ct, uint32_t b, float* lds) {
     using O = OpT<OP_BWD>;
@@ -253,19 +282,37 @@ __device__ __forceinline__ void conv_tile_bwd(const Params& p, const ConvTile& c
         const uint32_t ostride = ct.ci * ct.hw;
         constexpr int NI = kCtO * kCtRunW / 64;      // 36
         float t[NI];
+        // Element e = lane + 64 i sits at (o_l, k) = divmod(e, RLw).  Both byte offsets -- (o_l ostride + k) 4 from the uniform
+        // gradient base, (o_l 73 + k) 4 into the LDS slice -- are CARRIED from one access to the next (64 = sq RLw + sr: k += sr
+        // with one conditional wrap, 4 VALU per access) instead of being formed from e by a magic division and 64-bit
+        // address arithmetic each time (9 + 7): a quarter of the kernel's vector instructions went there.
+        const CtStep st = ct_step(g, ostride);
+        {
+            uint32_t k = st.k0, goff = st.g0;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const uint32_t e = g.lane + 64u * (uint32_t)i;
-            const uint32_t ec = e < E ? e : 0u;                  // clamp: the loads stay unconditional (E > 0 whenever a lane is valid)
-            const uint32_t o_l = (ec * g.M) >> 20, k = ec - o_l * g.RLw;
-            t[i] = src[o_l * ostride + k];
+            for (int i = 0; i < NI; ++i) {
+                const uint32_t e = g.lane + 64u * (uint32_t)i;
+                // clamped to the slice's first word: the loads stay unconditional (E > 0 whenever a lane is valid)
+                t[i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + (e < E ? goff : 0u));
+                k += st.sr;
+                const bool wrap = k >= g.RLw;
+                k -= wrap ? g.RLw : 0u;
+                goff += wrap ? st.ginc1 : st.ginc0;
+            }
         }
+        {
+            uint32_t k = st.k0, loff = st.l0;
+            char* lwb = reinterpret_cast<char*>(lw);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const uint32_t e = g.lane + 64u * (uint32_t)i;
-            if (e < E) {
-                const uint32_t o_l = (e * g.M) >> 20, k = e - o_l * g.RLw;
-                lw[o_l * kCtStrideW + k] = t[i];
+            for (int i = 0; i < NI; ++i) {
+                const uint32_t e = g.lane + 64u * (uint32_t)i;
+                // unconditional: a word past the slice's data goes to the pad word of row 0 (column 72 is never read) -- a
+                // predicated write costs a compare, an exec save / restore and a branch each
+                *reinterpret_cast<float*>(lwb + (e < E ? loff : (uint32_t)kCtRunW * 4u)) = t[i];
+                k += st.sr;
+                const bool wrap = k >= g.RLw;
+                k -= wrap ? g.RLw : 0u;
+                loff += wrap ? st.linc1 : st.linc0;
             }
         }
         __builtin_amdgcn_wave_barrier();
