@@ -5,8 +5,8 @@ custom loss terms and the scale update of anuunchin/learned-quantization, behind
 reference's own Python layer surface, executed by hand-written HIP kernels through the C ABI of
 ``include/lq_hip.h``.  See DESIGN.md / INTEGRATION.md.
 """
-from .descriptor import ORIENTATIONS, group_descriptor, scale_shape
-from .layers import (CustomConv2DLayer, CustomConv2DLayerNoBias, CustomDenseLayer, CustomQuantizedScaleLayer,
+from .descriptor import ORIENTATIONS, group_descriptor, memory_descriptor, memory_order, scale_shape
+from .layers import (default_kernel_storage, CustomConv2DLayer, CustomConv2DLayerNoBias, CustomDenseLayer, CustomQuantizedScaleLayer,
                      L2, MinValueConstraint, RandomNormal, SCALE_INIT, custom_layers_of, eps_float32, l2,
                      reset_layer_names)
 from .losses import SCCEDifference, SCCEInverse, SCCEMaxBin, sparse_categorical_crossentropy

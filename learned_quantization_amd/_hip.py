@@ -14,6 +14,8 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
+from .descriptor import memory_order
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LQ_HIP_LIB overrides the library path (development: experiment builds of the same ABI)
 LIB_PATH = os.environ.get("LQ_HIP_LIB") or os.path.join(_HERE, "csrc", "liblq_hip.so")
@@ -163,7 +165,15 @@ def check(rc: int, what: str) -> None:
         raise LQError(f"{what} failed: {lib.lq_status_string(rc).decode()} ({rc}): {msg}")
 
 
-def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+def same_layout(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Same shape and the same element order in memory (strides of unit axes address nothing and are ignored)."""
+    return a.shape == b.shape and all(d == 1 or x == y for d, x, y in zip(a.shape, a.stride(), b.stride()))
+
+
+def require_device_f32(t: torch.Tensor, name: str, dense_ok: bool = False, like: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Checks device / dtype and returns a tensor the kernels can read: contiguous by default; ``dense_ok``: a dense permutation
+    of a contiguous array is kept as it is (conv kernels stored in OIHW order behind an HWIO shape: the caller describes the
+    groups in memory order, descriptor.memory_descriptor); ``like``: the element order of that tensor (copied into it if needed)."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
     if not t.is_cuda:
@@ -179,7 +189,13 @@ def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
             f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: this library runs one "
             "process per GPU -- call torch.cuda.set_device(...) (or use `with torch.cuda.device(...)`) before using its ops"
         )
-    return t if t.is_contiguous() else t.contiguous()
+    if like is not None:
+        if t.shape != like.shape:
+            raise ValueError(f"{name} shape {tuple(t.shape)} != parameter shape {tuple(like.shape)}")
+        return t if same_layout(t, like) else torch.empty_like(like).copy_(t)
+    if t.is_contiguous() or (dense_ok and memory_order(t.shape, t.stride()) is not None):
+        return t
+    return t.contiguous()
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -23,7 +23,7 @@ from typing import List, Optional
 import torch
 
 from . import _hip
-from .descriptor import group_descriptor
+from .descriptor import memory_descriptor
 from .layers import CustomDenseLayer, _ConvBase, custom_layers_of
 
 
@@ -57,8 +57,11 @@ class FakeQuantBatch:
                 e.layer, e.slot, e.param, e.nested = layer, slot, param, nested
                 _hip.require_device_f32(param.data, "parameter")
                 _hip.require_device_f32(nested.scale.data, "scale")
-                if not param.data.is_contiguous():
-                    raise ValueError("parameters must be contiguous")
+                # a dense permutation of the logical axes (conv kernels stored OIHW, layers.py kernel_storage) is described in
+                # memory order; outputs and gradients carry the parameter's strides
+                e.desc = memory_descriptor(tuple(param.shape), param.data.stride(), tuple(nested.scale.shape))
+                if e.desc is None:
+                    raise ValueError("parameters must be dense (contiguous, or a permutation of a contiguous array)")
                 e.out = torch.empty_like(param.data)
                 e.shape = tuple(param.shape)
                 # write straight into an existing gradient buffer (e.g. a DataParallel bucket view) when there is one
@@ -70,12 +73,12 @@ class FakeQuantBatch:
                     e.ds = torch.zeros_like(nested.scale.data)
                 e.m = torch.zeros_like(nested.scale.data)
                 e.v = torch.zeros_like(nested.scale.data)
-                e.desc = group_descriptor(tuple(param.shape), tuple(nested.scale.shape))
                 # conv kernels of nested-quantization layers: the forward launch also emits the OIHW tensor MIOpen consumes and
                 # the scale-gradient launch reads MIOpen's OIHW weight gradient, writing dP back in HWIO order (lq_hip.h:
                 # lq_fq_forward_oihw) -- no transposition launches around the convolutions
                 e.out_oihw = e.dp = e.conv = None
-                if oihw and slot == 0 and isinstance(layer, _ConvBase) and nested.penalty_threshold is not None:
+                if (oihw and slot == 0 and isinstance(layer, _ConvBase) and nested.penalty_threshold is not None
+                        and param.data.is_contiguous()):          # HWIO-stored kernels only: an OIHW-stored one needs no companion
                     kh, kw, ci, co = (int(d) for d in param.shape)
                     e.conv = (kh * kw, ci, co)
                     e.out_oihw = torch.empty((co, ci, kh, kw), dtype=torch.float32, device=param.device)
@@ -156,7 +159,7 @@ class FakeQuantBatch:
                     raise RuntimeError("scale_grads_from_param_grads: a quantised parameter has no gradient")
                 self._ptrs[i] = None
                 continue
-            g = _hip.require_device_f32(g, "parameter gradient")
+            g = _hip.require_device_f32(g, "parameter gradient", like=e.param.data)
             keep.append(g)
             self._ptrs[i] = g.data_ptr()
         _hip.check(lib.lq_batch_scale_grad(self._handle, self._ptrs, _hip.ptr(self.ws), self.ws.numel(),
@@ -186,8 +189,8 @@ class FakeQuantBatch:
                 g = e.param.grad
                 if g is None:
                     g = e.param.grad = torch.zeros_like(e.param.data)
-                if not g.is_contiguous():
-                    raise ValueError("parameter gradients must be contiguous")
+                if not _hip.same_layout(g, e.param.data):       # a hand-assigned gradient: bring it into the parameter's element order
+                    g = e.param.grad = torch.empty_like(e.param.data).copy_(g)
                 grads[i] = g.data_ptr()
         kind_flag = self._KINDS[kind] | (_hip.LQ_PENALTY_ACCUMULATE_DS if accumulate_ds else 0)
         _hip.check(lib.lq_batch_penalty_grads(self._handle, kind_flag, coeff, grads, _hip.ptr(self.ws), self.ws.numel(),
@@ -251,7 +254,7 @@ class _BatchFn(torch.autograd.Function):
                 d = torch.zeros_like(e.param.data)
             elif oihw_used and i in batch._oihw_pos:
                 raise RuntimeError("FakeQuantBatch: conv kernels must all be consumed through the same layout in one step")
-            d = _hip.require_device_f32(d, "dy")
+            d = _hip.require_device_f32(d, "dy", like=None if i in gathered else e.param.data)
             keep.append(d)
             batch._ptrs[i] = d.data_ptr()
         fn = lib.lq_batch_scale_grad_oihw if oihw_used else lib.lq_batch_scale_grad

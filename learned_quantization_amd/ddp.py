@@ -30,6 +30,8 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import torch
 import torch.distributed as dist
 
+from .descriptor import memory_order
+
 
 class GradBucket:
     """Flat fp32 bucket over a fixed parameter list; grads become views into it.  Every view starts on a 256-byte
@@ -52,7 +54,9 @@ class GradBucket:
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.views = []
         for p, n, o in zip(self.params, self.sizes, self.offsets):
-            v = self.flat[o:o + n].view_as(p)
+            # the view carries the parameter's own strides (a conv kernel shaped HWIO and stored OIHW keeps that order in the
+            # bucket): gradient and parameter are then read by the kernels with one descriptor
+            v = self.flat[o:o + n].view_as(p) if p.is_contiguous() else torch.as_strided(self.flat, p.shape, p.stride(), o)
             self.views.append(v)
             p.grad = v            # autograd accumulates in place into the bucket
 
@@ -135,7 +139,11 @@ class DataParallel:
         self._avg = _avg_op(group) if self._collectives else None
         if broadcast and dist.is_initialized() and self._collectives:
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t.data, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                d = t.data
+                if not d.is_contiguous():     # a dense permutation (conv kernels stored OIHW): the contiguous view of the same memory
+                    order = memory_order(d.shape, d.stride())
+                    d = d.permute(order) if order is not None else d
+                dist.broadcast(d, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if mode == "B":
             for _, nested in self._nq_pairs():
                 nested.defer_scale_grad = True        # backward skips the local K2+K3 launch (ops._NestedQuantFn)

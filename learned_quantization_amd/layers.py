@@ -15,12 +15,21 @@ Mirrors /root/reference/MNIST/nested_quantization_layer/custom_components/custom
   CustomConv2DLayerNoBias(...)  .kernel .nested_q_k_layer
       /root/reference/CIFAR-10/paper_implementation/custom_components/custom_layers.py:299-365
 
-Parameters are stored in the REFERENCE's layouts -- Dense ``W`` = (in, out), conv ``kernel`` =
+Parameters have the REFERENCE's shapes -- Dense ``W`` = (in, out), conv ``kernel`` =
 HWIO (kh, kw, ci, co) -- so ``orientation`` means the same axes as in the reference
 (rowwise = axis 0, columnwise = axis 1, channelwise = axis 2 = input channels), the loss terms
 and callbacks see the same shapes, and the integer export is byte-compatible.  The matmul /
 convolution themselves are stock (rocBLAS / MIOpen through torch) and out of scope; only
 the fake-quant of W/kernel/b runs in this package's HIP kernels.
+
+``kernel_storage`` (conv layers; not in the reference) chooses the MEMORY order behind the HWIO shape:
+  "oihw" (default)  the kernel's elements lie in the order MIOpen consumes.  ``kernel.permute(3, 2, 0, 1)`` is a contiguous
+                    OIHW tensor, so the fake-quantised kernel goes to the convolution as it is written, MIOpen's weight
+                    gradient IS dP (custom_layers.py:118, 0 bytes), and the fake-quant kernels stream both (8 B per element
+                    forward, 8 B backward -- SURVEY 8d's figures) with the groups described in memory order
+                    (descriptor.memory_descriptor).  Index by index every tensor equals the HWIO-stored one.
+  "hwio"            contiguous HWIO like a TensorFlow variable (zero-copy hand-over of the raw buffer to code that expects
+                    that); the kernels then transpose through LDS tiles (lq_fq_forward_oihw / lq_fq_scale_grad_oihw).
 
 Like Keras layers, these build lazily on first call (``build(input_shape)``); pass
 ``input_shape=`` (Dense: last dim, Conv: channels) to build eagerly so an optimizer can be
@@ -243,6 +252,26 @@ class CustomDenseLayer(_HostLayer):
     forward = call
 
 
+_KERNEL_STORAGE = ["oihw"]
+
+
+class default_kernel_storage:
+    """``with default_kernel_storage("hwio"): model = build_model(...)`` -- the memory order of conv kernels built inside."""
+
+    def __init__(self, storage: str):
+        if storage not in ("oihw", "hwio"):
+            raise ValueError("kernel_storage must be 'oihw' or 'hwio'")
+        self.storage = storage
+
+    def __enter__(self):
+        _KERNEL_STORAGE.append(self.storage)
+        return self
+
+    def __exit__(self, *exc):
+        _KERNEL_STORAGE.pop()
+        return False
+
+
 def _pair(v) -> Tuple[int, int]:
     if isinstance(v, int):
         return (v, v)
@@ -264,9 +293,14 @@ class _ConvBase(_HostLayer):
     def __init__(self, seed=None, penalty_threshold=None, orientation="scalar", initializer=None, filters=None,
                  kernel_size=(3, 3), strides=(1, 1), padding="same", name=None, regularizer=None,
                  trained_weights=None, *, penalty_rate=None, input_shape=None, data_format="NCHW", device=None,
-                 **kwargs):
+                 kernel_storage=None, **kwargs):
         super().__init__()
         self.seed = seed
+        if kernel_storage is None:
+            kernel_storage = _KERNEL_STORAGE[-1]
+        if kernel_storage not in ("oihw", "hwio"):
+            raise ValueError("kernel_storage must be 'oihw' or 'hwio'")
+        self.kernel_storage = kernel_storage
         self.nested_q_k_layer = _nested(penalty_threshold, penalty_rate, orientation)      # NQ-L:293-295
         if self._has_bias:
             self.nested_q_b_layer = _nested(penalty_threshold, penalty_rate, "scalar")     # NQ-L:296-298
@@ -302,6 +336,8 @@ class _ConvBase(_HostLayer):
         else:
             k = self._init_value(self.initializer, kernel_shape, device)
             b = self._init_value(self.initializer, (self.filters,), device) if self._has_bias else None
+        if self.kernel_storage == "oihw":          # same shape and values, elements in (co, ci, kh, kw) order
+            k = k.permute(3, 2, 0, 1).contiguous().permute(2, 3, 1, 0)
         self.kernel = nn.Parameter(k)
         self.nested_q_k_layer.build(kernel_shape, device=device)
         if self._has_bias:
@@ -322,13 +358,16 @@ class _ConvBase(_HostLayer):
             w = pre[2]                                   # the batch emitted the OIHW companion with the same launch
         elif pre is not None:
             w = pre[0].permute(3, 2, 0, 1)                                                 # HWIO -> OIHW view
-        elif nested.built and nested.penalty_threshold is not None and self.kernel.is_cuda:
+        elif (self.kernel_storage == "hwio" and nested.built and nested.penalty_threshold is not None
+              and self.kernel.is_cuda and self.kernel.is_contiguous()):
             # NQ-L:340 with K1 writing the OIHW tensor MIOpen consumes (and K2 reading its OIHW weight gradient): same
             # values as nested(kernel).permute(3, 2, 0, 1), without the two transposition launches
             w = ops.my_custom_gradient_oihw(self.kernel, nested.scale, nested.penalty_threshold,
                                             defer_scale_grad=nested.defer_scale_grad)
         else:
-            w = nested(self.kernel).permute(3, 2, 0, 1)                                    # NQ-L:340; HWIO -> OIHW view
+            # NQ-L:340; HWIO -> OIHW view -- contiguous when the kernel is stored "oihw": MIOpen takes it as it is and its
+            # weight gradient comes back with the parameter's own strides
+            w = nested(self.kernel).permute(3, 2, 0, 1)
         if self.padding == "SAME":
             ph = _same_padding(x.shape[-2], self.kernel_size[0], self.strides[0])
             pw = _same_padding(x.shape[-1], self.kernel_size[1], self.strides[1])

@@ -262,8 +262,13 @@ class ResNet50Like(nn.Module):
         return softmax(self.out(torch.mean(x, dim=(2, 3))), dim=1)
 
 
-def build_model(config: str, **kw) -> nn.Module:
-    """config: 'mnist' (C1), 'cifar' (C2/C4), 'imagenette' (C3), 'resnet50' (C5, extension)."""
+def build_model(config: str, kernel_storage: str = None, **kw) -> nn.Module:
+    """config: 'mnist' (C1), 'cifar' (C2/C4), 'imagenette' (C3), 'resnet50' (C5, extension).
+    ``kernel_storage``: memory order of the conv kernels, "oihw" (default) or "hwio" (layers.py)."""
+    if kernel_storage is not None:
+        from .layers import default_kernel_storage
+        with default_kernel_storage(kernel_storage):
+            return build_model(config, **kw)
     if config == "resnet50":
         return ResNet50Like(**kw)
     if config == "mnist":

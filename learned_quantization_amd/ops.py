@@ -17,7 +17,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _hip
-from .descriptor import group_descriptor
+from .descriptor import group_descriptor, memory_descriptor
 
 _QDTYPES = {
     torch.float32: _hip.LQ_Q_F32,
@@ -30,21 +30,29 @@ def _desc(parameter: torch.Tensor, scale: torch.Tensor) -> Tuple[int, int, int]:
     return group_descriptor(tuple(parameter.shape), tuple(scale.shape))
 
 
+def _param(parameter: torch.Tensor, scale: torch.Tensor):
+    """(P, s, descriptor) as the kernels read them.  A parameter whose memory is a dense permutation of its logical axes -- a
+    conv kernel shaped HWIO (custom_layers.py:321) and stored OIHW, layers.py ``kernel_storage`` -- is NOT copied: the groups
+    are described in memory order, and every same-shaped output is allocated with the parameter's strides, so that logically
+    (index by index) the results are those of the contiguous tensor."""
+    p = _hip.require_device_f32(parameter, "parameter", dense_ok=True)
+    s = _hip.require_device_f32(scale, "scale")
+    return p, s, memory_descriptor(tuple(p.shape), p.stride(), tuple(s.shape))
+
+
 # --------------------------------------------------------------------------- raw wrappers
 def fq_forward(parameter: torch.Tensor, scale: torch.Tensor, q_dtype: Optional[torch.dtype] = None,
                want_out: bool = True):
     """K1.  Returns ``out`` (and ``q`` when ``q_dtype`` is given).  custom_layers.py:55-60."""
     lib = _hip.load()
-    p = _hip.require_device_f32(parameter, "parameter")
-    s = _hip.require_device_f32(scale, "scale")
-    outer, G, inner = _desc(p, s)
+    p, s, (outer, G, inner) = _param(parameter, scale)
     out = torch.empty_like(p) if want_out else None
     q = None
     qd = _hip.LQ_Q_NONE
     if q_dtype is not None:
         if q_dtype not in _QDTYPES:
             raise TypeError(f"q_dtype must be one of {list(_QDTYPES)}, got {q_dtype}")
-        q = torch.empty(p.shape, dtype=q_dtype, device=p.device)
+        q = torch.empty_like(p, dtype=q_dtype)
         qd = _QDTYPES[q_dtype]
     if out is None and q is None:
         raise ValueError("nothing to compute: want_out=False and q_dtype=None")
@@ -64,12 +72,8 @@ def fq_scale_grad(parameter: torch.Tensor, scale: torch.Tensor, dy: torch.Tensor
                   return_parts: bool = False):
     """K2+K3: the hand-written scale gradient of custom_layers.py:62-118.  Returns ds (shape of scale)."""
     lib = _hip.load()
-    p = _hip.require_device_f32(parameter, "parameter")
-    s = _hip.require_device_f32(scale, "scale")
-    d = _hip.require_device_f32(dy, "dy")
-    if d.shape != p.shape:
-        raise ValueError(f"dy shape {tuple(d.shape)} != parameter shape {tuple(p.shape)}")
-    outer, G, inner = _desc(p, s)
+    p, s, (outer, G, inner) = _param(parameter, scale)
+    d = _hip.require_device_f32(dy, "dy", like=p)
     ds = torch.empty_like(s)
     parts = torch.empty(3 * G, dtype=torch.float32, device=p.device) if return_parts else None
     ws = _hip.workspace_for(p.device, outer, G, inner)
@@ -85,14 +89,12 @@ def fq_fwd_bwd_fused(parameter: torch.Tensor, scale: torch.Tensor, dy: torch.Ten
                      out: Optional[torch.Tensor] = None, ds: Optional[torch.Tensor] = None):
     """K4: forward and NQ backward in one pass over P (benchmark path).  Returns (out, ds)."""
     lib = _hip.load()
-    p = _hip.require_device_f32(parameter, "parameter")
-    s = _hip.require_device_f32(scale, "scale")
-    d = _hip.require_device_f32(dy, "dy")
-    if d.shape != p.shape:
-        raise ValueError(f"dy shape {tuple(d.shape)} != parameter shape {tuple(p.shape)}")
-    outer, G, inner = _desc(p, s)
+    p, s, (outer, G, inner) = _param(parameter, scale)
+    d = _hip.require_device_f32(dy, "dy", like=p)
     if out is None:
         out = torch.empty_like(p)
+    elif not _hip.same_layout(out, p):
+        raise ValueError("out must have the parameter's shape and strides")
     if ds is None:
         ds = torch.empty_like(s)
     ws = _hip.workspace_for(p.device, outer, G, inner)
@@ -325,9 +327,7 @@ class _MaxBinTerm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, parameter, scale):
         lib = _hip.load()
-        p = _hip.require_device_f32(parameter, "parameter")
-        s = _hip.require_device_f32(scale, "scale")
-        outer, G, inner = _desc(p, s)
+        p, s, (outer, G, inner) = _param(parameter, scale)
         mb = torch.empty(G, dtype=torch.float32, device=p.device)
         ties = torch.empty(G, dtype=torch.int32, device=p.device)
         term = torch.empty((), dtype=torch.float32, device=p.device)
@@ -359,9 +359,7 @@ class _DifferenceTerm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, parameter, scale):
         lib = _hip.load()
-        p = _hip.require_device_f32(parameter, "parameter")
-        s = _hip.require_device_f32(scale, "scale")
-        outer, G, inner = _desc(p, s)
+        p, s, (outer, G, inner) = _param(parameter, scale)
         term = torch.empty((), dtype=torch.float32, device=p.device)
         ws = _hip.workspace_for(p.device, outer, G, inner)
         _hip.check(lib.lq_penalty_difference_fwd(_hip.ptr(p), _hip.ptr(s), _hip.ptr(term), _hip.ptr(ws), ws.numel(),

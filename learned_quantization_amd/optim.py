@@ -60,9 +60,10 @@ class KerasAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.requires_grad]
             for p in ps:
-                _hip.require_device_f32(p.data, "parameter")
-                if not p.data.is_contiguous():
-                    raise ValueError("KerasAdam needs contiguous parameters")
+                # element-wise update: any dense memory order will do as long as w, m, v and the gradient share it
+                d = p.data
+                if _hip.require_device_f32(d, "parameter", dense_ok=True) is not d:
+                    raise ValueError("KerasAdam needs dense parameters (contiguous, or a permutation of a contiguous array)")
                 st = self.state[p]
                 if "m" not in st:
                     st["m"] = torch.zeros_like(p.data)
@@ -114,7 +115,7 @@ class KerasAdam(torch.optim.Optimizer):
                 if g is None:
                     gptrs[i] = None
                 else:
-                    g = _hip.require_device_f32(g, "gradient")
+                    g = _hip.require_device_f32(g, "gradient", like=p.data)
                     keep.append(g)
                     gptrs[i] = g.data_ptr()
             b1, b2 = group["betas"]

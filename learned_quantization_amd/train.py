@@ -63,13 +63,16 @@ class Trainer:
     def __init__(self, config="cifar", mode="nq", value=1e-11, orientation="channelwise", loss: Optional[str] = None,
                  lr=1e-4, seed=42, device=None, ddp_mode="A", log_dir="logs", graph=False, batched=False,
                  bucket_mb: float = 25.0, overlap: bool = True, graph_collectives: Optional[bool] = None,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, kernel_storage: str = "oihw"):
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         torch.manual_seed(seed)
         L.reset_layer_names()
         self.config = config
         self.mode = mode
-        self.model = build_model(config, mode=mode, value=value, seed=seed, orientation=orientation, device=self.device)
+        # conv kernels shaped HWIO like the reference's, stored in the order MIOpen consumes (layers.py kernel_storage): the
+        # fake-quantised kernel goes to the convolution as written and its weight gradient is dP
+        self.model = build_model(config, mode=mode, value=value, seed=seed, orientation=orientation, device=self.device,
+                                 kernel_storage=kernel_storage)
         self.model.to(self.device)
         self.custom_layers = L.custom_layers_of(self.model)
         self.loss_obj = None
@@ -274,6 +277,8 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl", help="nccl = RCCL over xGMI (default); gloo + --share-gpu rehearses N>1 on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--batched", action="store_true", help="multi-tensor launches for all fake-quant ops of a step (lq_batch_*)")
+    ap.add_argument("--kernel-storage", choices=["oihw", "hwio"], default="oihw",
+                    help="memory order of the conv kernels behind their HWIO shape (layers.py)")
     ap.add_argument("--channels-last", action="store_true",
                     help="feed NHWC-strided batches (torch.channels_last): MIOpen's fp32 igemm kernels are NHWC; measured "
                          "+17 %% on the ResNet-18-like config, -17 %% on the small CIFAR CNN")
@@ -309,7 +314,7 @@ def main(argv=None):
         value = (args.value_coarse, args.value)
     tr = Trainer(args.config, args.mode, value, args.orientation, args.loss, seed=args.seed, device=dev,
                  ddp_mode=args.ddp_mode, graph=args.graph, batched=args.batched, bucket_mb=args.bucket_mb,
-                 graph_collectives=args.graph_collectives, force_collectives=args.force_dist)
+                 graph_collectives=args.graph_collectives, force_collectives=args.force_dist, kernel_storage=args.kernel_storage)
     do_step = tr.step_graphed if args.graph else tr.step
     g = torch.Generator(device=dev).manual_seed(args.seed + rank)
     batches = [synthetic_batch(args.config, args.batch, dev, g) for _ in range(4)]

@@ -17,10 +17,10 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _model(dev, config, orient, mode="nq", value=1e-3, seed=3):
+def _model(dev, config, orient, mode="nq", value=1e-3, seed=3, kernel_storage=None):
     import learned_quantization_amd as lq
     lq.reset_layer_names()
-    m = lq.build_model(config, mode=mode, value=value, seed=seed, orientation=orient, device=dev)
+    m = lq.build_model(config, mode=mode, value=value, seed=seed, orientation=orient, device=dev, kernel_storage=kernel_storage)
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
         for s in lq.scale_parameters(m):
@@ -209,14 +209,17 @@ def test_oihw_companion_ops_are_bit_identical_to_permuting(dev, orient):
             assert torch.equal(ds, lq.fq_scale_grad(k, s, dy_hwio, lam)), f"{shape} {orient} lam={lam}: ds"
 
 
-def test_conv_layer_hands_miopen_the_oihw_companion(dev):
-    """CustomConv2DLayer.call (NQ-L:338-350) through the companion path == explicit fake-quant + permute + conv2d."""
+@pytest.mark.parametrize("storage", ["hwio", "oihw"])
+def test_conv_layer_hands_miopen_the_oihw_companion(dev, storage):
+    """CustomConv2DLayer.call (NQ-L:338-350) == explicit fake-quant + permute + conv2d: through the companion path for a kernel
+    stored HWIO, and with no transposition anywhere for a kernel stored OIHW (the gradient then has the parameter's strides)."""
     import learned_quantization_amd as lq
     import torch.nn.functional as F
     lq.reset_layer_names()
     layer = lq.CustomConv2DLayer(seed=0, penalty_threshold=1e-3, orientation="channelwise", initializer=lq.RandomNormal(seed=3),
                                  filters=16, kernel_size=(3, 3), strides=(1, 1), padding="same", name="c", regularizer=None,
-                                 input_shape=8, device=dev)
+                                 input_shape=8, device=dev, kernel_storage=storage)
+    assert layer.kernel.is_contiguous() == (storage == "hwio") and layer.kernel.permute(3, 2, 0, 1).is_contiguous() == (storage == "oihw")
     with torch.no_grad():
         layer.nested_q_k_layer.scale.uniform_(1e-3, 1e-2)
     x = torch.randn(4, 8, 12, 12, device=dev)
@@ -226,7 +229,8 @@ def test_conv_layer_hands_miopen_the_oihw_companion(dev):
     y_ref = F.conv2d(x, qk.permute(3, 2, 0, 1).contiguous(), None, 1, 1) + qb.view(1, -1, 1, 1)
     assert torch.equal(y, y_ref)
     y.square().mean().backward()
-    assert layer.kernel.grad is not None and layer.kernel.grad.shape == layer.kernel.shape and layer.kernel.grad.is_contiguous()
+    assert layer.kernel.grad is not None and layer.kernel.grad.shape == layer.kernel.shape
+    assert layer.kernel.grad.stride() == layer.kernel.stride()
     assert layer.nested_q_k_layer.scale.grad is not None and bool((layer.nested_q_k_layer.scale.grad <= 0).all())
 
 
@@ -237,7 +241,7 @@ def test_batch_emits_oihw_companions_and_reads_oihw_gradients(dev, hwio_out):
     ``hwio_out=False`` (the trainer's form): the HWIO output is not materialised where the LDS tile writes the companion; the
     batch hands out the permuted view of the companion in its place."""
     import learned_quantization_amd as lq
-    m = _model(dev, "cifar", "channelwise")
+    m = _model(dev, "cifar", "channelwise", kernel_storage="hwio")
     batch = lq.FakeQuantBatch(m, hwio_out=hwio_out)
     assert hwio_out or sum(e.out is None for e in batch.entries) == 6, "every 3x3 kernel of the CIFAR CNN takes the tile path"
     batch.quantize_all()

@@ -306,3 +306,60 @@ def test_shipped_library_reads_no_environment(tmp_path):
     for value in ("0", "1", "3", "128"):
         env = dict(os.environ, **{k: value for k in knobs})
         assert subprocess.check_output([sys.executable, "-c", probe], text=True, env=env) == base, f"LQ_TUNE_* = {value} changed the plan"
+
+
+def test_memory_order_descriptor_matches_the_logical_groups():
+    """descriptor.memory_descriptor: for any dense permutation of the axes, element i IN MEMORY belongs to group
+    (i // inner) % G -- checked against the logical index along the scale's axis, element by element."""
+    import itertools
+    from learned_quantization_amd.descriptor import group_descriptor, memory_descriptor, memory_order, scale_shape
+    rng = np.random.default_rng(0)
+    for shape in [(3, 3, 4, 5), (1, 1, 6, 7), (2, 5), (7, 1, 3, 2), (4,)]:
+        for perm in itertools.permutations(range(len(shape))):
+            mem = torch.empty([shape[a] for a in perm])                       # memory axes, slowest first
+            t = mem.permute([perm.index(a) for a in range(len(shape))])       # logical view of that memory
+            assert tuple(t.shape) == shape
+            order = memory_order(t.shape, t.stride())
+            assert order is not None and [shape[a] for a in order if shape[a] != 1] == [shape[a] for a in perm if shape[a] != 1]
+            for orient in ("rowwise", "columnwise", "channelwise", "scalar"):
+                try:
+                    ss = scale_shape(shape, orient) if orient == "scalar" or {"rowwise": 0, "columnwise": 1, "channelwise": 2}[orient] < len(shape) else None
+                except IndexError:
+                    ss = None
+                if ss is None:
+                    continue
+                outer, G, inner = memory_descriptor(t.shape, t.stride(), ss)
+                assert outer * G * inner == t.numel()
+                # logical group index of every element, laid out in memory order
+                axis = [i for i, d in enumerate(ss) if d != 1]
+                idx = np.indices(shape)[axis[0]] if axis and len(ss) == len(shape) else np.zeros(shape, dtype=np.int64)
+                flat_mem = np.transpose(idx, perm).reshape(-1)
+                want = (np.arange(t.numel()) // inner) % G
+                assert np.array_equal(flat_mem, want), (shape, perm, orient)
+                if t.is_contiguous():
+                    assert (outer, G, inner) == group_descriptor(shape, ss)
+    # not a dense permutation: gaps, broadcast strides
+    assert memory_order((4, 5), (10, 1)) is None and memory_order((4, 5), (0, 1)) is None
+    assert memory_descriptor((4, 5), (10, 1), (4, 1)) is None
+
+
+def test_conv_kernel_storage_is_a_layout_not_a_shape():
+    import learned_quantization_amd as lq
+    for st in ("oihw", "hwio"):
+        lq.reset_layer_names()
+        layer = lq.CustomConv2DLayer(seed=0, penalty_threshold=1e-3, orientation="channelwise", initializer=lq.RandomNormal(seed=3),
+                                     filters=6, kernel_size=(3, 3), strides=(1, 1), padding="same", name="c", regularizer=None,
+                                     input_shape=4, kernel_storage=st)
+        assert tuple(layer.kernel.shape) == (3, 3, 4, 6) and tuple(layer.nested_q_k_layer.scale.shape) == (1, 1, 4, 1)
+        assert layer.kernel.is_contiguous() == (st == "hwio") and layer.kernel.permute(3, 2, 0, 1).is_contiguous() == (st == "oihw")
+        if st == "oihw":
+            ref = layer.kernel.detach().clone()
+        else:
+            assert torch.equal(layer.kernel.detach(), ref), "same values from the same initializer for either storage"
+    with pytest.raises(ValueError):
+        lq.CustomConv2DLayer(seed=0, penalty_threshold=1e-3, initializer=lq.RandomNormal(seed=3), filters=6, kernel_storage="ohwi")
+    with lq.default_kernel_storage("hwio"):
+        m = lq.build_model("cifar", mode="nq", value=1e-11, seed=1, orientation="channelwise")
+    assert all(p.is_contiguous() for p in m.parameters())
+    m = lq.build_model("cifar", mode="nq", value=1e-11, seed=1, orientation="channelwise")
+    assert any(not p.is_contiguous() for p in m.parameters()) and all(p.dim() == 4 for p in m.parameters() if not p.is_contiguous())

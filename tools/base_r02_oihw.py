@@ -17,7 +17,7 @@ assert "_base_r02" in lq.__file__, lq.__file__
 config, orient = sys.argv[1].split(":")
 dev = torch.device("cuda:0")
 lam = 1e-11
-model = lq.build_model(config, mode="nq", value=(1e-10, lam) if config == "resnet50" else lam, seed=42, orientation=orient, device=dev)
+model = lq.build_model(config, mode="nq", value=(1e-10, lam) if config == "resnet50" else lam, seed=42, orientation=orient, device=dev, kernel_storage="hwio")
 batch = lq.FakeQuantBatch(model)
 g = torch.Generator(device=dev).manual_seed(42)
 dys = [torch.randn(e.out.shape, device=dev, generator=g) * 1e-3 for e in batch.entries]

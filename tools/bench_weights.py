@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--only", default=None, help="config:orientation, e.g. mnist:columnwise")
     ap.add_argument("--abi-only", action="store_true", help="time only the raw batch ABI (profiling runs)")
     ap.add_argument("--companion-only", action="store_true", help="conv kernels emit the OIHW companion only (hwio_out=False: what the trainer uses)")
+    ap.add_argument("--kernel-storage", default="hwio", choices=["hwio", "oihw"],
+                    help="memory order of the conv kernels (layers.py): hwio = the LDS-tile companion path of the *_oihw column; "
+                         "oihw = stored as MIOpen consumes them, plain streaming launches (the *_oihw column then equals the plain one)")
     ap.add_argument("--ablate", type=int, default=0, help="development library only (LQ_HIP_LIB=.../liblq_hip_dev.so): lq_dev_set_ablate mask")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -55,11 +58,11 @@ def main():
             lq.reset_layer_names()
             # resnet50 (BASELINE configs[4], 108 tensors, 23.5 M el): "mixed" thresholds, 1e-10 on the 3x3 kernels, 1e-11 elsewhere
             model = lq.build_model(config, mode="nq", value=(1e-10, lam) if config == "resnet50" else lam, seed=42,
-                                   orientation=orient, device=dev)
+                                   orientation=orient, device=dev, kernel_storage=args.kernel_storage)
             batch = lq.FakeQuantBatch(model, hwio_out=not args.companion_only)
             opt = lq.BatchedScaleAdam(batch)
             g = torch.Generator(device=dev).manual_seed(42)
-            dys = [torch.randn(e.shape, device=dev, generator=g) * 1e-3 for e in batch.entries]
+            dys = [torch.empty_like(e.param.data).normal_(generator=g) * 1e-3 for e in batch.entries]      # the parameter's strides
             n_el = sum(e.param.numel() for e in batch.entries)
 
             def batched_step():
@@ -98,7 +101,7 @@ def main():
                 lib.lq_batch_scale_adam(batch._handle, 1e-4, 0.9, 0.999, 1e-7, 1, None, 0, sp)
 
             row = {"config": config, "orientation": orient, "tensors": len(batch.entries), "elements": n_el,
-                   "companion_only": bool(args.companion_only),
+                   "companion_only": bool(args.companion_only), "kernel_storage": args.kernel_storage,
                    "us_per_step_batched_abi": timed(batched_abi_only, args.steps, dev),
                    "us_per_step_batched_abi_oihw": timed(batched_abi_oihw, args.steps, dev)}
             if not args.abi_only:
