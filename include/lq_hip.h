@@ -162,12 +162,13 @@ int lq_q_absmax_over_axis(const float* P, const float* s, float* result,
  *                          launches; `dy` (optional, [n] device pointers, indexed like the descriptors)
  *                          overrides the descriptors' dy -- the upstream gradients move every step
  *   lq_batch_scale_adam  = lq_scale_adam_step(_dev) of every scale with Adam state in ONE launch
+ *   lq_batch_scale_grad_step = the two above in the two launches of the first
  * Results are bit-identical to the single-tensor entry points for tensors below 4 M elements (same device
  * code and reduction geometry); larger tensors differ only by fp32 summation order (~1e-7 relative).
  * lq_batch_create/destroy allocate/free the table (hipMalloc; not stream-ordered, never inside a capture);
  * the other calls only enqueue.  lambda = NaN marks an STE-only tensor (custom_loss_terms variant).        */
 typedef struct lq_tensor_desc {
-    const float* P;      /* parameter, contiguous fp32                          */
+    const float* P;      /* parameter, dense fp32; (outer, G, inner) describes its elements in MEMORY order */
     const float* s;      /* scale [G]                                            */
     const float* dy;     /* default upstream gradient (may be NULL)              */
     float* out;          /* fake-quantised output (may be NULL next to out_oihw when lq_conv_tile_supported) */
@@ -195,6 +196,14 @@ int lq_batch_scale_grad(const lq_batch* batch, const float* const* dy, void* ws,
 int lq_batch_scale_grad_oihw(const lq_batch* batch, const float* const* dy, void* ws, size_t ws_bytes, void* stream);
 int lq_batch_scale_adam(const lq_batch* batch, double lr, double beta1, double beta2, double eps, int64_t step,
                         const int64_t* step_dev, int mode, void* stream);
+/* lq_batch_scale_grad (dy_oihw = 0) or lq_batch_scale_grad_oihw (dy_oihw = 1) followed by lq_batch_scale_adam, in the TWO
+ * launches of the former: the finalize that emits ds[g] applies the Adam step and the MinValueConstraint to s[g] itself
+ * (custom_layers.py:116, 158).  Same ds, m, v and s, bit for bit, as the two calls one after the other.  For the step in which
+ * nothing reads or changes ds between its computation and the update (nested-quantization training without a loss term and
+ * without an exchange of ds); every tensor of the batch must have lambda, ds and Adam state (LQ_EINVAL otherwise).          */
+int lq_batch_scale_grad_step(const lq_batch* batch, const float* const* dy, int dy_oihw, void* ws, size_t ws_bytes,
+                             double lr, double beta1, double beta2, double eps, int64_t step, const int64_t* step_dev,
+                             int mode, void* stream);
 
 /* Custom-loss-term gradients of every tensor of the batch in 2-4 launches
  *   (CIFAR-10/custom_loss_terms/custom_components/custom_loss_functions.py:75-116, 161-195, 240-275).

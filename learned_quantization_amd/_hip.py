@@ -67,6 +67,7 @@ SIGNATURES.update({
     "lq_batch_workspace_bytes": (_c_sz, [_c_p]),
     "lq_batch_forward": (_c_int, [_c_p, _c_p]),
     "lq_batch_scale_grad": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
+    "lq_batch_scale_grad_step": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_int, _c_p, _c_sz, _c_d, _c_d, _c_d, _c_d, _c_i64, _c_p, _c_int, _c_p]),
     "lq_batch_scale_grad_oihw": (_c_int, [_c_p, ctypes.POINTER(_c_p), _c_p, _c_sz, _c_p]),
     "lq_conv_workspace_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "lq_conv_tile_supported": (_c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),

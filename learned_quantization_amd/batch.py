@@ -41,6 +41,7 @@ class FakeQuantBatch:
         layers = custom_layers_of(model_or_layers) if isinstance(model_or_layers, torch.nn.Module) else list(model_or_layers)
         self.layers = layers
         self._external_grads = False
+        self._fused_opt = None               # BatchedScaleAdam(fused=True): the scale-gradient finalize applies the Adam step itself
         self.defer_scale_grads = False       # exact data-parallel mode: backward skips ds, scale_grads_from_param_grads() follows
         self.entries: List[_Entry] = []
         for layer in layers:
@@ -145,6 +146,24 @@ class FakeQuantBatch:
                                         outs[self._oihw_pos[ik]] if ik in self._oihw_pos else None)
         return outs[:n]
 
+    def _scale_grad_call(self, oihw: bool):
+        """lq_batch_scale_grad(_oihw), or -- a fused optimizer attached -- lq_batch_scale_grad_step: same launches, the finalize
+        also applies the scales' Adam step."""
+        lib = _hip.load()
+        opt = self._fused_opt
+        sp = _hip.stream_ptr(self.device)
+        if opt is None:
+            fn = lib.lq_batch_scale_grad_oihw if oihw else lib.lq_batch_scale_grad
+            _hip.check(fn(self._handle, self._ptrs, _hip.ptr(self.ws), self.ws.numel(), sp), "lq_batch_scale_grad")
+            return
+        step, step_dev = opt._advance()
+        h = self.hyper
+        md = {"keras": _hip.LQ_ADAM_KERAS, "torch": _hip.LQ_ADAM_TORCH}[h["mode"]]
+        _hip.check(lib.lq_batch_scale_grad_step(self._handle, self._ptrs, 1 if oihw else 0, _hip.ptr(self.ws), self.ws.numel(),
+                                                h["lr"], h["betas"][0], h["betas"][1], h["eps"], int(step or 0), _hip.ptr(step_dev),
+                                                md, sp), "lq_batch_scale_grad_step")
+        opt._applied = True
+
     # ------------------------------------------------------------------ exact data-parallel mode (ddp.py, mode B)
     def scale_grads_from_param_grads(self):
         """ds of every nested-quantization tensor from its parameter's CURRENT gradient, in two launches.  After the
@@ -162,8 +181,7 @@ class FakeQuantBatch:
             g = _hip.require_device_f32(g, "parameter gradient", like=e.param.data)
             keep.append(g)
             self._ptrs[i] = g.data_ptr()
-        _hip.check(lib.lq_batch_scale_grad(self._handle, self._ptrs, _hip.ptr(self.ws), self.ws.numel(),
-                                           _hip.stream_ptr(self.device)), "lq_batch_scale_grad")
+        self._scale_grad_call(False)
         for e in self.entries:
             if e.nested.penalty_threshold is not None:
                 e.nested.scale.grad = e.ds
@@ -257,9 +275,7 @@ class _BatchFn(torch.autograd.Function):
             d = _hip.require_device_f32(d, "dy", like=None if i in gathered else e.param.data)
             keep.append(d)
             batch._ptrs[i] = d.data_ptr()
-        fn = lib.lq_batch_scale_grad_oihw if oihw_used else lib.lq_batch_scale_grad
-        _hip.check(fn(batch._handle, batch._ptrs, _hip.ptr(batch.ws), batch.ws.numel(), _hip.stream_ptr(batch.device)),
-                   "lq_batch_scale_grad")
+        batch._scale_grad_call(oihw_used)
         grads = [None]
         for i, (e, d) in enumerate(zip(batch.entries, keep)):
             grads.append(e.dp if i in gathered else d)             # dP is dy itself (custom_layers.py:118), in HWIO order
@@ -280,9 +296,21 @@ class _BatchFn(torch.autograd.Function):
 class BatchedScaleAdam:
     """Optimizer facade over ``FakeQuantBatch.scale_adam_step`` (K6 for every scale in one launch)."""
 
-    def __init__(self, batch: FakeQuantBatch, capturable: bool = False):
+    def __init__(self, batch: FakeQuantBatch, capturable: bool = False, fused: bool = False):
+        """``fused``: the batch's scale-gradient finalize applies this optimizer's step in the same launch
+        (lq_batch_scale_grad_step) and ``step()`` only acknowledges it.  For training steps in which nothing reads or changes the
+        scale gradients between backward and ``step()`` -- no loss term, no exchange of ds (single process, or exact data-parallel
+        mode B where ds is computed after the exchange); every tensor must be a nested-quantization one."""
         self.batch = batch
         self.capturable = capturable
+        self._applied = False
+        if fused:
+            if any(e.nested.penalty_threshold is None for e in batch.entries):
+                raise ValueError("a fused scale update needs nested-quantization layers throughout (every scale gets its gradient "
+                                 "from the batch's own scale-gradient pass)")
+            if batch._external_grads:
+                raise ValueError("a fused scale update cannot be combined with gradient buffers that are exchanged (bucket views)")
+            batch._fused_opt = self
         self._step = 0
         self._step_t = torch.zeros(1, dtype=torch.int64, device=batch.device) if capturable else None
         self.param_groups = [{"params": [e.nested.scale for e in batch.entries]}]
@@ -291,8 +319,21 @@ class BatchedScaleAdam:
         for e in self.batch.entries:
             e.nested.scale.grad = None
 
+    def _advance(self):
+        """(host step, device step tensor) of the update that is about to be applied."""
+        if self.capturable:
+            self._step_t += 1
+            return None, self._step_t
+        self._step += 1
+        return self._step, None
+
     @torch.no_grad()
     def step(self):
+        if self.batch._fused_opt is self:
+            if not self._applied:
+                raise RuntimeError("BatchedScaleAdam(fused=True).step() without a backward pass of the batch since the last step")
+            self._applied = False            # the finalize of this step's scale-gradient pass has already updated the scales
+            return
         # only scales that actually received a gradient this step are updated by Adam in the reference too; with the
         # nested-quantization op every scale does.  STE-only scales are updated from the loss-term gradients.
         for e in self.batch.entries:
@@ -301,9 +342,5 @@ class BatchedScaleAdam:
                 e.ds.zero_()
             elif g.data_ptr() != e.ds.data_ptr():
                 e.ds.copy_(g)                                      # loss-term gradients arrive in autograd-owned tensors
-        if self.capturable:
-            self._step_t += 1
-            self.batch.scale_adam_step(step_dev=self._step_t)
-        else:
-            self._step += 1
-            self.batch.scale_adam_step(step=self._step)
+        step, step_dev = self._advance()
+        self.batch.scale_adam_step(step=step, step_dev=step_dev)

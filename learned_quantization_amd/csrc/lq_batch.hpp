@@ -22,6 +22,10 @@ struct Task {
     ConvTile ct;              // mode == MODE_CONV_TILE
     float* ds;                // scale gradient output [G]
     float* dp;                // dP in HWIO order (conv kernels with an OIHW companion), else NULL
+    float* am;                // Adam moments of the scale (fused update in the finalize), or NULL
+    float* av;
+    float amin;               // MinValueConstraint of the scale
+    int pad2;
     float* mb;                // batch-owned per-group max(|P|/s)      (MaxBin penalty)
     uint32_t* ties;           // batch-owned per-group tie counts
     int mode, vec, lpr_log2, pad0;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(BS) void k_batch_finalize(const Task* __restrict__ 
     f.o1 = nullptr;
     f.o2 = (OP == OP_MAXBIN_FWD) ? t.ties : nullptr;
     f.accum = accum;
-    finalize_block_body<OP, BS>(p, f, (int64_t)(blockIdx.x - t.first_group));
+    finalize_block_body<OP, BS>(p, f, (int64_t)(blockIdx.x - t.first_group), (int)threadIdx.x);
 }
 
 // Scale gradients of the MaxBin (kind 0) and Inverse (kind 2) penalty terms for every group of every tensor:
@@ -170,31 +174,88 @@ struct AdamTask {
     int pad;
 };
 
-__global__ __launch_bounds__(kBlock) void k_batch_adam(const AdamTask* __restrict__ tasks, float lr, float b1, float b2, double lr_d,
-                                                       double b1_d, double b2_d, float f0, float f1, float eps,
-                                                       const int64_t* step_dev, int64_t step_host, int mode) {
-    const AdamTask t = tasks[blockIdx.x];
-    const int64_t step = step_dev ? step_dev[0] : step_host;
-    float alpha = 0.f, step_size = 0.f, sq_bc2 = 1.f;
-    if (mode == LQ_ADAM_KERAS) {
-        const float b1p = powf(b1, (float)step), b2p = powf(b2, (float)step);
-        alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+// Hyper-parameters of one Adam step (kernel argument).  `on` = 0: the finalize only emits ds.
+struct AdamHyper {
+    double lr_d, b1_d, b2_d;
+    const int64_t* step_dev;
+    int64_t step_host;
+    float lr, b1, b2, f0, f1, eps;
+    int mode, on;
+};
+struct AdamCoef {
+    float alpha, step_size, sq_bc2;
+};
+__device__ __forceinline__ AdamCoef adam_coef(const AdamHyper& h) {
+    const int64_t step = h.step_dev ? h.step_dev[0] : h.step_host;
+    AdamCoef c;
+    c.alpha = 0.f;
+    c.step_size = 0.f;
+    c.sq_bc2 = 1.f;
+    if (h.mode == LQ_ADAM_KERAS) {
+        const float b1p = powf(h.b1, (float)step), b2p = powf(h.b2, (float)step);
+        c.alpha = h.lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
     } else {
-        const double bc1 = 1.0 - pow(b1_d, (double)step), bc2 = 1.0 - pow(b2_d, (double)step);
-        step_size = (float)(lr_d / bc1);
-        sq_bc2 = (float)sqrt(bc2);
+        const double bc1 = 1.0 - pow(h.b1_d, (double)step), bc2 = 1.0 - pow(h.b2_d, (double)step);
+        c.step_size = (float)(h.lr_d / bc1);
+        c.sq_bc2 = (float)sqrt(bc2);
     }
-    for (int64_t i = threadIdx.x; i < t.n; i += kBlock) {
-        const float g = t.ds[i];
-        float mi = t.m[i], vi = t.v[i], w = t.s[i];
-        mi = mi + (g - mi) * f0;
-        vi = vi + (g * g - vi) * f1;
-        if (mode == LQ_ADAM_KERAS) w = w - (mi * alpha) / (sqrtf(vi) + eps);
-        else w = w - step_size * (mi / (sqrtf(vi) / sq_bc2 + eps));
-        w = (w < t.min_value) ? t.min_value : w;
-        t.m[i] = mi;
-        t.v[i] = vi;
-        t.s[i] = w;
+    return c;
+}
+// one scale element: Adam (Keras 2.11 or torch arithmetic) + MinValueConstraint (custom_layers.py:42-43, 158)
+__device__ __forceinline__ void adam_element(const AdamHyper& h, const AdamCoef& c, float g, float* m, float* v, float* s, int64_t i, float min_value) {
+    float mi = m[i], vi = v[i], w = s[i];
+    mi = mi + (g - mi) * h.f0;
+    vi = vi + (g * g - vi) * h.f1;
+    if (h.mode == LQ_ADAM_KERAS) w = w - (mi * c.alpha) / (sqrtf(vi) + h.eps);
+    else w = w - c.step_size * (mi / (sqrtf(vi) / c.sq_bc2 + h.eps));
+    w = (w < min_value) ? min_value : w;
+    m[i] = mi;
+    v[i] = vi;
+    s[i] = w;
+}
+
+__global__ __launch_bounds__(kBlock) void k_batch_adam(const AdamTask* __restrict__ tasks, AdamHyper h) {
+    const AdamTask t = tasks[blockIdx.x];
+    const AdamCoef c = adam_coef(h);
+    for (int64_t i = threadIdx.x; i < t.n; i += kBlock) adam_element(h, c, t.ds[i], t.m, t.v, t.s, i, t.min_value);
+}
+
+// Finalize of the scale-gradient pass for every group of every tensor, and -- `ah.on` -- the Adam step of that group's scale in
+// the same launch (nothing may read or change ds in between: no loss term, no exchange of ds; the caller decides).
+//   BS = 64:  a WAVE per group, four groups per 256-thread block (no group of the batch has more than 256 partials: the
+//             summation order is that of the 64-thread finalize of the single-tensor entry points);
+//   BS = 256: a block per group.
+// The group's task comes from a per-group table (one 2-byte load instead of a binary search over the prefix array: 5-7 dependent
+// loads at the head of every block were a third of this launch).
+template <int OP, int BS>
+__global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict__ tasks, const uint16_t* __restrict__ group_task,
+                                                          uint32_t total_groups, uint32_t* ws, AdamHyper ah) {
+    static_assert(OpT<OP>::kStdMerge, "wave-per-group finalize needs the DPP merge (no block barrier)");
+    const uint32_t gg = BS == 64 ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x;
+    if (gg >= total_groups) return;          // wave-uniform; the BS = 64 form has no block barrier
+    const int tid = BS == 64 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const Task& t = tasks[group_task[gg]];
+    Params p = t.p;
+    p.pa = ws + t.ws_off;
+    p.pb = p.pa + t.np_pad;
+    p.pc = reinterpret_cast<double*>(p.pb + t.np_pad);
+    FinGeom f;
+    f.groups = p.G;
+    f.gstride = t.gstride;
+    f.n1 = t.n1;
+    f.stride1 = t.stride1;
+    f.n2 = t.n2;
+    f.count = t.count;
+    f.o0 = t.ds;
+    f.o1 = nullptr;
+    f.o2 = nullptr;
+    f.accum = 0;
+    const int64_t g = (int64_t)(gg - t.first_group);
+    finalize_block_body<OP, BS>(p, f, g, tid);
+    // the thread that emitted ds[g] (lane 63 of a one-wave finalize, thread 0 otherwise) reads its own store back
+    if (ah.on && t.am && tid == (BS == 64 ? 63 : 0)) {
+        const AdamCoef c = adam_coef(ah);
+        adam_element(ah, c, t.ds[g], t.am, t.av, const_cast<float*>(t.p.s), g, t.amin);
     }
 }
 

@@ -1405,6 +1405,7 @@ struct lq_task_table {                    // one device-resident task table
     lq::Task* d = nullptr;
     uint32_t* prefix_d = nullptr;         // [n] first block of every task, then [n] first group
     uint16_t* block_task_d = nullptr;     // [blocks] task of every traversal block
+    uint16_t* group_task_d = nullptr;     // [groups] task of every group (scale-gradient tables)
     uint32_t blocks = 0, groups = 0;
     bool has_tile = false;                // some task runs the conv tile (needs the tile kernel's LDS)
     int64_t ws_words = 0;
@@ -1596,6 +1597,15 @@ static int finish_table(lq_task_table& tb, bool bwd) {
     if (e == hipSuccess) e = hipMemcpy(tb.prefix_d, prefix.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&tb.block_task_d, bt.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemcpy(tb.block_task_d, bt.data(), bt.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && bwd && gp > 0) {
+        std::vector<uint16_t> gt((size_t)gp);
+        for (size_t k = 0; k < n; ++k) {
+            const uint64_t end = k + 1 < n ? prefix[n + k + 1] : gp;
+            for (uint64_t g = prefix[n + k]; g < end; ++g) gt[g] = (uint16_t)k;
+        }
+        e = hipMalloc(&tb.group_task_d, gt.size() * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMemcpy(tb.group_task_d, gt.data(), gt.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc(&tb.d, n * sizeof(Task));
     if (e != hipSuccess) return fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
     return LQ_OK;
@@ -1612,7 +1622,9 @@ static void free_table(lq_task_table& tb) {
     if (tb.d) (void)hipFree(tb.d);
     if (tb.prefix_d) (void)hipFree(tb.prefix_d);
     if (tb.block_task_d) (void)hipFree(tb.block_task_d);
+    if (tb.group_task_d) (void)hipFree(tb.group_task_d);
     tb.block_task_d = nullptr;
+    tb.group_task_d = nullptr;
     tb.d = nullptr;
     tb.prefix_d = nullptr;
 }
@@ -1661,9 +1673,19 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
             }
             Task tb;
             if ((rc = fill_task(tb, d, true, false, b->bwd))) break;
+            if (d.m && d.v) {           // the finalize can apply the scale's Adam step itself (lq_batch_scale_grad_step)
+                tb.am = d.m;
+                tb.av = d.v;
+                tb.amin = d.min_value;
+            }
             b->bwd.h.push_back(tb);
             b->bwd.index.push_back(i);
             if ((rc = fill_task(tb, d, true, true, b->bwd_o))) break;
+            if (d.m && d.v) {
+                tb.am = d.m;
+                tb.av = d.v;
+                tb.amin = d.min_value;
+            }
             b->bwd_o.h.push_back(tb);
             b->bwd_o.index.push_back(i);
         }
@@ -1757,19 +1779,52 @@ static bool batch_wide_finalize(const std::vector<lq::Task>& h) {
 }
 extern "C" {
 
-static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream, bool oihw);
+static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream, bool oihw, const AdamHyper& ah);
+
+static AdamHyper adam_hyper(double lr, double beta1, double beta2, double eps, int64_t step, const int64_t* step_dev, int mode, int on) {
+    AdamHyper h;
+    memset(&h, 0, sizeof(h));
+    h.lr_d = lr;
+    h.b1_d = beta1;
+    h.b2_d = beta2;
+    h.step_dev = step_dev;
+    h.step_host = step;
+    h.lr = (float)lr;
+    h.b1 = (float)beta1;
+    h.b2 = (float)beta2;
+    h.f0 = (float)(1.0 - beta1);
+    h.f1 = (float)(1.0 - beta2);
+    h.eps = (float)eps;
+    h.mode = mode;
+    h.on = on;
+    return h;
+}
 
 int lq_batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream) {
-    return batch_scale_grad(b, dy, ws, ws_bytes, stream, false);
+    return batch_scale_grad(b, dy, ws, ws_bytes, stream, false, adam_hyper(0, 0, 0, 0, 1, nullptr, LQ_ADAM_KERAS, 0));
 }
 
 int lq_batch_scale_grad_oihw(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream) {
-    return batch_scale_grad(b, dy, ws, ws_bytes, stream, b && b->has_perm);
+    return batch_scale_grad(b, dy, ws, ws_bytes, stream, b && b->has_perm, adam_hyper(0, 0, 0, 0, 1, nullptr, LQ_ADAM_KERAS, 0));
+}
+
+int lq_batch_scale_grad_step(const lq_batch* b, const float* const* dy, int dy_oihw, void* ws, size_t ws_bytes, double lr, double beta1,
+                             double beta2, double eps, int64_t step, const int64_t* step_dev, int mode, void* stream) {
+    if (!b) return fail(LQ_EINVAL, "lq_batch_scale_grad_step: NULL batch");
+    if (!step_dev && step < 1) return fail(LQ_EINVAL, "lq_batch_scale_grad_step: step is 1-based");
+    if (mode != LQ_ADAM_KERAS && mode != LQ_ADAM_TORCH) return fail(LQ_EINVAL, "lq_batch_scale_grad_step: bad mode %d", mode);
+    // every scale the separate Adam launch would update must be one whose gradient this pass computes
+    size_t with_state = 0;
+    for (const lq::Task& t : b->bwd.h) with_state += t.am ? 1 : 0;
+    if (with_state != b->adam_h.size() || with_state != b->bwd.h.size())
+        return fail(LQ_EINVAL, "lq_batch_scale_grad_step: every tensor of the batch needs lambda, ds and Adam state (%zu of %zu have them)",
+                    with_state, b->adam_h.size() > b->bwd.h.size() ? b->adam_h.size() : b->bwd.h.size());
+    return batch_scale_grad(b, dy, ws, ws_bytes, stream, dy_oihw && b->has_perm, adam_hyper(lr, beta1, beta2, eps, step, step_dev, mode, 1));
 }
 
 }  // extern "C"
 
-static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream, bool oihw) {
+static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream, bool oihw, const AdamHyper& ah) {
     if (!b) return fail(LQ_EINVAL, "lq_batch_scale_grad: NULL batch");
     const lq_task_table& tb = oihw ? b->bwd_o : b->bwd;
     if (tb.h.empty()) return LQ_OK;
@@ -1801,11 +1856,11 @@ static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws,
     int rc = check_hip("batch scale-grad launch");
     if (rc) return rc;
     if (batch_wide_finalize(tb.h))
-        hipLaunchKernelGGL((k_batch_finalize<OP_BWD, 256>), dim3(tb.groups), dim3(256), 0, (hipStream_t)stream, tb.d, tb.prefix_d + nt, nt,
-                           (uint32_t*)ws, 0);
+        hipLaunchKernelGGL((k_batch_finalize_t<OP_BWD, 256>), dim3(tb.groups), dim3(256), 0, (hipStream_t)stream, tb.d, tb.group_task_d,
+                           tb.groups, (uint32_t*)ws, ah);
     else
-        hipLaunchKernelGGL((k_batch_finalize<OP_BWD>), dim3(tb.groups), dim3(64), 0, (hipStream_t)stream, tb.d, tb.prefix_d + nt, nt,
-                           (uint32_t*)ws, 0);
+        hipLaunchKernelGGL((k_batch_finalize_t<OP_BWD, 64>), dim3((tb.groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, tb.d,
+                           tb.group_task_d, tb.groups, (uint32_t*)ws, ah);
     return check_hip("batch finalize launch");
 }
 
@@ -1864,9 +1919,8 @@ int lq_batch_scale_adam(const lq_batch* b, double lr, double beta1, double beta2
     if (b->adam_h.empty()) return LQ_OK;
     if (!step_dev && step < 1) return fail(LQ_EINVAL, "lq_batch_scale_adam: step is 1-based");
     if (mode != LQ_ADAM_KERAS && mode != LQ_ADAM_TORCH) return fail(LQ_EINVAL, "lq_batch_scale_adam: bad mode %d", mode);
-    hipLaunchKernelGGL(k_batch_adam, dim3((unsigned)b->adam_h.size()), dim3(kBlock), 0, (hipStream_t)stream, b->adam_d, (float)lr,
-                       (float)beta1, (float)beta2, lr, beta1, beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-                       step_dev, step, mode);
+    hipLaunchKernelGGL(k_batch_adam, dim3((unsigned)b->adam_h.size()), dim3(kBlock), 0, (hipStream_t)stream, b->adam_d,
+                       adam_hyper(lr, beta1, beta2, eps, step, step_dev, mode, 1));
     return check_hip("batch adam launch");
 }
 

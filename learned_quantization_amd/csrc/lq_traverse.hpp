@@ -620,19 +620,19 @@ __device__ __forceinline__ void dpp_row_reduce_w(AccW& acc) {
 // One block of BS threads per group.  Index arithmetic is 32-bit whenever the partial count allows (a 64-bit
 // division per loaded partial used to dominate this kernel).
 template <int OP, int BS>
-__device__ __forceinline__ void finalize_block_body(const Params& p, const FinGeom& f, int64_t g) {
+__device__ __forceinline__ void finalize_block_body(const Params& p, const FinGeom& f, int64_t g, int tid) {      // tid: 0..BS-1
     using O = OpT<OP>;
     const int64_t n = f.n1 * f.n2;
     const int64_t gbase = g * f.gstride;
     AccW acc = O::template init<AccW>();
     if (n < 0x7fffffffll) {
         const uint32_t n32 = (uint32_t)n, n2 = (uint32_t)f.n2;
-        for (uint32_t k = threadIdx.x; k < n32; k += BS) {
+        for (uint32_t k = (uint32_t)tid; k < n32; k += BS) {
             const uint32_t i1 = k / n2, i2 = k - i1 * n2;
             O::merge(acc, load_partial<O>(p, gbase + (int64_t)i1 * f.stride1 + i2));
         }
     } else {
-        for (int64_t k = threadIdx.x; k < n; k += BS) {
+        for (int64_t k = tid; k < n; k += BS) {
             const int64_t i1 = k / f.n2, i2 = k - i1 * f.n2;
             O::merge(acc, load_partial<O>(p, gbase + i1 * f.stride1 + i2));
         }
@@ -644,7 +644,7 @@ __device__ __forceinline__ void finalize_block_body(const Params& p, const FinGe
         dpp_row_reduce_w(acc);
         dpp_step_w<0x142, 0xa>(acc);
         dpp_step_w<0x143, 0xc>(acc);
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const int lane = tid & 63, wid = tid >> 6;
         if (NW > 1) {
             if (lane == 63) {
                 sa[wid] = acc.a;
@@ -665,13 +665,13 @@ __device__ __forceinline__ void finalize_block_body(const Params& p, const FinGe
         }
     } else {
         block_reduce<O, AccW, BS>(acc);
-        if (threadIdx.x == 0) FinT<OP>::emit(p, f, g, acc);
+        if (tid == 0) FinT<OP>::emit(p, f, g, acc);
     }
 }
 
 template <int OP, int BS>
 __global__ __launch_bounds__(BS) void k_finalize_block(Params p, FinGeom f) {
-    finalize_block_body<OP, BS>(p, f, (int64_t)blockIdx.x);
+    finalize_block_body<OP, BS>(p, f, (int64_t)blockIdx.x, (int)threadIdx.x);
 }
 
 // One thread per group (few partials per group, possibly very many groups).

@@ -106,7 +106,10 @@ class Trainer:
             if self.dp is not None:
                 self.dp.zero_grad()          # makes scale.grad the bucket views the batch will write into
             self.batch = FakeQuantBatch(self.model, lr=lr, hwio_out=False)     # the convolutions consume the OIHW companions only
-            self.scale_opt = BatchedScaleAdam(self.batch, capturable=graph)
+            # nothing touches ds between its computation and the scales' update when there is no loss term and ds is not
+            # exchanged (one process, or exact mode B): the finalize then applies the Adam step itself (one launch fewer)
+            fused = self.loss_obj is None and (self.dp is None or ddp_mode == "B")
+            self.scale_opt = BatchedScaleAdam(self.batch, capturable=graph, fused=fused)
             if self.dp is not None:
                 self.dp.attach_batch(self.batch)
         else:

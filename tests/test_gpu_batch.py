@@ -265,3 +265,52 @@ def test_batch_emits_oihw_companions_and_reads_oihw_gradients(dev, hwio_out):
         assert torch.equal(l.b.grad, d_b)
         assert torch.equal(l.nested_q_b_layer.scale.grad,
                            lq.fq_scale_grad(l.b.data, l.nested_q_b_layer.scale.data, d_b, l.nested_q_b_layer.penalty_threshold))
+
+
+@pytest.mark.parametrize("config,orient,storage", [("cifar", "channelwise", "oihw"), ("cifar", "rowwise", "hwio"), ("mnist", "columnwise", None),
+                                                   ("imagenette", "channelwise", "oihw"), ("imagenette", "scalar", "hwio")])
+def test_fused_scale_update_equals_scale_grad_then_adam(dev, config, orient, storage):
+    """lq_batch_scale_grad_step (the finalize applies Adam + MinValueConstraint to the scale whose gradient it has just emitted,
+    custom_layers.py:116, 158) == lq_batch_scale_grad followed by lq_batch_scale_adam: ds, moments and scales bit for bit, over
+    three steps, for either kernel storage (the HWIO one through the OIHW companions and the LDS tiles)."""
+    import learned_quantization_amd as lq
+    res = {}
+    for fused in (False, True):
+        m = _model(dev, config, orient, value=1e-4, kernel_storage=storage)
+        batch = lq.FakeQuantBatch(m, hwio_out=False)
+        opt = lq.BatchedScaleAdam(batch, fused=fused)
+        g = torch.Generator(device=dev).manual_seed(21)
+        hist = []
+        for step in range(3):
+            opt.zero_grad()
+            batch.quantize_all()
+            outs, dys = [], []
+            for l in lq.custom_layers_of(m):
+                qk, qb, qo = l._q_pre
+                for o in ((qo if qo is not None else qk), qb):
+                    if o is not None:
+                        outs.append(o)
+                        dys.append(torch.randn(tuple(o.shape), device=dev, generator=g) * 1e-3)
+            torch.autograd.backward(outs, dys)
+            ds = [e.nested.scale.grad.clone() for e in batch.entries]
+            opt.step()
+            hist.append((ds, [e.nested.scale.detach().clone() for e in batch.entries], [e.m.clone() for e in batch.entries],
+                         [e.v.clone() for e in batch.entries]))
+        res[fused] = hist
+    for step, (a, b) in enumerate(zip(res[False], res[True])):
+        for what, xa, xb in zip(("ds", "scale", "m", "v"), a, b):
+            for i, (ta, tb) in enumerate(zip(xa, xb)):
+                assert torch.equal(ta, tb), f"step {step} tensor {i}: {what}"
+    assert any(float((s1 - s0).abs().max()) > 0 for s0, s1 in zip(res[True][0][1], res[True][2][1])), "the scales moved"
+
+
+def test_fused_scale_update_is_refused_where_something_sits_between_gradient_and_update(dev):
+    import learned_quantization_amd as lq
+    m = _model(dev, "cifar", "channelwise", mode="cl", value=1e-7)          # STE-only layers: ds comes from the loss term
+    with pytest.raises(ValueError, match="nested-quantization"):
+        lq.BatchedScaleAdam(lq.FakeQuantBatch(m), fused=True)
+    m = _model(dev, "mnist", "rowwise")
+    b = lq.FakeQuantBatch(m)
+    opt = lq.BatchedScaleAdam(b, fused=True)
+    with pytest.raises(RuntimeError, match="without a backward"):
+        opt.step()
