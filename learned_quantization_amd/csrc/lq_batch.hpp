@@ -202,13 +202,16 @@ __device__ __forceinline__ AdamCoef adam_coef(const AdamHyper& h) {
     return c;
 }
 // one scale element: Adam (Keras 2.11 or torch arithmetic) + MinValueConstraint (custom_layers.py:42-43, 158)
-__device__ __forceinline__ void adam_element(const AdamHyper& h, const AdamCoef& c, float g, float* m, float* v, float* s, int64_t i, float min_value) {
-    float mi = m[i], vi = v[i], w = s[i];
+__device__ __forceinline__ void adam_value(const AdamHyper& h, const AdamCoef& c, float g, float& mi, float& vi, float& w, float min_value) {
     mi = mi + (g - mi) * h.f0;
     vi = vi + (g * g - vi) * h.f1;
     if (h.mode == LQ_ADAM_KERAS) w = w - (mi * c.alpha) / (sqrtf(vi) + h.eps);
     else w = w - c.step_size * (mi / (sqrtf(vi) / c.sq_bc2 + h.eps));
     w = (w < min_value) ? min_value : w;
+}
+__device__ __forceinline__ void adam_element(const AdamHyper& h, const AdamCoef& c, float g, float* m, float* v, float* s, int64_t i, float min_value) {
+    float mi = m[i], vi = v[i], w = s[i];
+    adam_value(h, c, g, mi, vi, w, min_value);
     m[i] = mi;
     v[i] = vi;
     s[i] = w;
@@ -222,19 +225,27 @@ __global__ __launch_bounds__(kBlock) void k_batch_adam(const AdamTask* __restric
 
 // Finalize of the scale-gradient pass for every group of every tensor, and -- `ah.on` -- the Adam step of that group's scale in
 // the same launch (nothing may read or change ds in between: no loss term, no exchange of ds; the caller decides).
-//   BS = 64:  a WAVE per group, four groups per 256-thread block (no group of the batch has more than 256 partials: the
-//             summation order is that of the 64-thread finalize of the single-tensor entry points);
-//   BS = 256: a block per group.
-// The group's task comes from a per-group table (one 2-byte load instead of a binary search over the prefix array: 5-7 dependent
-// loads at the head of every block were a third of this launch).
-template <int OP, int BS>
-__global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict__ tasks, const uint16_t* __restrict__ group_task,
-                                                          uint32_t total_groups, uint32_t* ws, AdamHyper ah) {
+// A 256-thread block serves FOUR groups of a task whose groups have at most 256 partials (a wave per group, no block barrier:
+// the summation order of the 64-thread finalize of the single-tensor entry points) or ONE group of a task with more (the
+// 256-thread finalize).  Which task and which first group a block serves comes from a per-block table (one 8-byte load
+// instead of a binary search over the prefix array: 5-7 dependent loads at the head of every block were a third of this launch).
+// The emitting thread fetches the scale's Adam state BEFORE it walks the partials, so that after the reduction only arithmetic
+// and three stores remain.
+struct FinBlock {
+    uint32_t task;        // bit 31: wide (one group per block)
+    uint32_t g0;          // first group of this block within the task
+};
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict__ tasks, const FinBlock* __restrict__ blocks, uint32_t* ws,
+                                                          AdamHyper ah) {
     static_assert(OpT<OP>::kStdMerge, "wave-per-group finalize needs the DPP merge (no block barrier)");
-    const uint32_t gg = BS == 64 ? blockIdx.x * 4u + (threadIdx.x >> 6) : blockIdx.x;
-    if (gg >= total_groups) return;          // wave-uniform; the BS = 64 form has no block barrier
-    const int tid = BS == 64 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
-    const Task& t = tasks[group_task[gg]];
+    const FinBlock fb = blocks[blockIdx.x];
+    const bool wide = (fb.task >> 31) != 0;
+    const Task& t = tasks[fb.task & 0x7fffffffu];
+    const int64_t g = (int64_t)fb.g0 + (wide ? 0 : (int64_t)(threadIdx.x >> 6));
+    if (g >= t.p.G) return;                  // wave-uniform, narrow form only (it has no block barrier)
+    const int tid = wide ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     Params p = t.p;
     p.pa = ws + t.ws_off;
     p.pb = p.pa + t.np_pad;
@@ -250,12 +261,22 @@ __global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict
     f.o1 = nullptr;
     f.o2 = nullptr;
     f.accum = 0;
-    const int64_t g = (int64_t)(gg - t.first_group);
-    finalize_block_body<OP, BS>(p, f, g, tid);
-    // the thread that emitted ds[g] (lane 63 of a one-wave finalize, thread 0 otherwise) reads its own store back
-    if (ah.on && t.am && tid == (BS == 64 ? 63 : 0)) {
-        const AdamCoef c = adam_coef(ah);
-        adam_element(ah, c, t.ds[g], t.am, t.av, const_cast<float*>(t.p.s), g, t.amin);
+    // the thread that will emit ds[g]: lane 63 of a one-wave finalize, thread 0 of the wide one
+    const bool update = ah.on && t.am && tid == (wide ? 0 : 63);
+    AdamCoef c;
+    float mi = 0.f, vi = 0.f, w = 0.f;
+    if (update) {
+        c = adam_coef(ah);
+        mi = t.am[g];
+        vi = t.av[g];
+        w = t.p.s[g];
+    }
+    const float dsg = wide ? finalize_block_body<OP, 256>(p, f, g, tid) : finalize_block_body<OP, 64>(p, f, g, tid);
+    if (update) {
+        adam_value(ah, c, dsg, mi, vi, w, t.amin);
+        t.am[g] = mi;
+        t.av[g] = vi;
+        const_cast<float*>(t.p.s)[g] = w;
     }
 }
 

@@ -1405,7 +1405,8 @@ struct lq_task_table {                    // one device-resident task table
     lq::Task* d = nullptr;
     uint32_t* prefix_d = nullptr;         // [n] first block of every task, then [n] first group
     uint16_t* block_task_d = nullptr;     // [blocks] task of every traversal block
-    uint16_t* group_task_d = nullptr;     // [groups] task of every group (scale-gradient tables)
+    lq::FinBlock* fin_blocks_d = nullptr; // [fin_blocks] task and first group of every finalize block (scale-gradient tables)
+    uint32_t fin_blocks = 0;
     uint32_t blocks = 0, groups = 0;
     bool has_tile = false;                // some task runs the conv tile (needs the tile kernel's LDS)
     int64_t ws_words = 0;
@@ -1598,13 +1599,17 @@ static int finish_table(lq_task_table& tb, bool bwd) {
     if (e == hipSuccess) e = hipMalloc(&tb.block_task_d, bt.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemcpy(tb.block_task_d, bt.data(), bt.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && bwd && gp > 0) {
-        std::vector<uint16_t> gt((size_t)gp);
+        // finalize blocks: four groups per block (a wave each) where a group has at most 256 partials, else a block per group
+        std::vector<FinBlock> fb;
         for (size_t k = 0; k < n; ++k) {
-            const uint64_t end = k + 1 < n ? prefix[n + k + 1] : gp;
-            for (uint64_t g = prefix[n + k]; g < end; ++g) gt[g] = (uint16_t)k;
+            const Task& t = tb.h[k];
+            const bool wide = t.n1 * t.n2 > 256;
+            for (int64_t g = 0; g < t.p.G; g += wide ? 1 : 4) fb.push_back({(uint32_t)k | (wide ? 0x80000000u : 0u), (uint32_t)g});
         }
-        e = hipMalloc(&tb.group_task_d, gt.size() * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipMemcpy(tb.group_task_d, gt.data(), gt.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+        if (fb.size() > 0x7fffffffull) return fail(LQ_EINVAL, "lq_batch_create: too many groups");
+        tb.fin_blocks = (uint32_t)fb.size();
+        e = hipMalloc(&tb.fin_blocks_d, fb.size() * sizeof(FinBlock));
+        if (e == hipSuccess) e = hipMemcpy(tb.fin_blocks_d, fb.data(), fb.size() * sizeof(FinBlock), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc(&tb.d, n * sizeof(Task));
     if (e != hipSuccess) return fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
@@ -1622,9 +1627,9 @@ static void free_table(lq_task_table& tb) {
     if (tb.d) (void)hipFree(tb.d);
     if (tb.prefix_d) (void)hipFree(tb.prefix_d);
     if (tb.block_task_d) (void)hipFree(tb.block_task_d);
-    if (tb.group_task_d) (void)hipFree(tb.group_task_d);
+    if (tb.fin_blocks_d) (void)hipFree(tb.fin_blocks_d);
     tb.block_task_d = nullptr;
-    tb.group_task_d = nullptr;
+    tb.fin_blocks_d = nullptr;
     tb.d = nullptr;
     tb.prefix_d = nullptr;
 }
@@ -1772,11 +1777,6 @@ int lq_batch_forward(const lq_batch* b, void* stream) {
 }
 
 }  // extern "C"
-static bool batch_wide_finalize(const std::vector<lq::Task>& h) {
-    for (const lq::Task& t : h)
-        if (t.n1 * t.n2 > 256) return true;
-    return false;
-}
 extern "C" {
 
 static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws, size_t ws_bytes, void* stream, bool oihw, const AdamHyper& ah);
@@ -1855,12 +1855,8 @@ static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws,
                            (uint32_t*)ws, pk, 1, cf);
     int rc = check_hip("batch scale-grad launch");
     if (rc) return rc;
-    if (batch_wide_finalize(tb.h))
-        hipLaunchKernelGGL((k_batch_finalize_t<OP_BWD, 256>), dim3(tb.groups), dim3(256), 0, (hipStream_t)stream, tb.d, tb.group_task_d,
-                           tb.groups, (uint32_t*)ws, ah);
-    else
-        hipLaunchKernelGGL((k_batch_finalize_t<OP_BWD, 64>), dim3((tb.groups + 3) / 4), dim3(256), 0, (hipStream_t)stream, tb.d,
-                           tb.group_task_d, tb.groups, (uint32_t*)ws, ah);
+    hipLaunchKernelGGL((k_batch_finalize_t<OP_BWD>), dim3(tb.fin_blocks), dim3(256), 0, (hipStream_t)stream, tb.d, tb.fin_blocks_d,
+                       (uint32_t*)ws, ah);
     return check_hip("batch finalize launch");
 }
 

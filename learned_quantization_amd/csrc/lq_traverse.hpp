@@ -530,7 +530,7 @@ struct FinT;
 
 template <>
 struct FinT<OP_BWD> {
-    __device__ static void emit(const Params& p, const FinGeom& f, int64_t g, const AccW& a) {
+    __device__ static float emit(const Params& p, const FinGeom& f, int64_t g, const AccW& a) {
         const float maxq = __uint_as_float(a.a);
         float mean;
         if (a.b == 0.0) {
@@ -538,12 +538,14 @@ struct FinT<OP_BWD> {
         } else {
             mean = (float)(a.c / f.count);                      // :87 / :113
         }
-        f.o0[g] = mean * maxq;                                  // :116
+        const float ds = mean * maxq;                           // :116
+        f.o0[g] = ds;
         if (f.o1) {
             f.o1[g] = maxq;
             f.o1[f.groups + g] = mean;
             f.o1[2 * f.groups + g] = (float)a.b;
         }
+        return ds;
     }
 };
 template <>
@@ -553,24 +555,27 @@ struct FinT<OP_BWD_PERM> : FinT<OP_BWD> {};
 
 template <>
 struct FinT<OP_MAXBIN_FWD> {
-    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
+    __device__ static float emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
         f.o0[g] = __uint_as_float(a.a);
         f.o2[g] = (uint32_t)(a.b > 4294967295.0 ? 4294967295.0 : a.b);
+        return 0.f;
     }
 };
 
 template <>
 struct FinT<OP_DIFF_FWD> {
-    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
+    __device__ static float emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
         f.o0[g] = (float)(a.c / f.count);                       // custom_loss_functions.py:175 reduce_mean
+        return 0.f;
     }
 };
 
 template <>
 struct FinT<OP_DIFF_BWD> {
-    __device__ static void emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
+    __device__ static float emit(const Params&, const FinGeom& f, int64_t g, const AccW& a) {
         const float v = (float)a.c;
         f.o0[g] = f.accum ? f.o0[g] + v : v;
+        return 0.f;
     }
 };
 
@@ -620,7 +625,9 @@ __device__ __forceinline__ void dpp_row_reduce_w(AccW& acc) {
 // One block of BS threads per group.  Index arithmetic is 32-bit whenever the partial count allows (a 64-bit
 // division per loaded partial used to dominate this kernel).
 template <int OP, int BS>
-__device__ __forceinline__ void finalize_block_body(const Params& p, const FinGeom& f, int64_t g, int tid) {      // tid: 0..BS-1
+__device__ __forceinline__ float finalize_block_body(const Params& p, const FinGeom& f, int64_t g, int tid) {     // tid: 0..BS-1; the
+    // emitting thread (lane 63 of a one-wave finalize, thread 0 otherwise) returns the value it wrote to o0[g]
+    float ret = 0.f;
     using O = OpT<OP>;
     const int64_t n = f.n1 * f.n2;
     const int64_t gbase = g * f.gstride;
@@ -658,15 +665,16 @@ __device__ __forceinline__ void finalize_block_body(const Params& p, const FinGe
                 r.b = lane < NW ? sb[lane] : 0.0;
                 r.c = lane < NW ? sc[lane] : 0.0;
                 dpp_row_reduce_w(r);
-                if (lane == 0) FinT<OP>::emit(p, f, g, r);
+                if (lane == 0) ret = FinT<OP>::emit(p, f, g, r);
             }
         } else if (lane == 63) {
-            FinT<OP>::emit(p, f, g, acc);
+            ret = FinT<OP>::emit(p, f, g, acc);
         }
     } else {
         block_reduce<O, AccW, BS>(acc);
-        if (tid == 0) FinT<OP>::emit(p, f, g, acc);
+        if (tid == 0) ret = FinT<OP>::emit(p, f, g, acc);
     }
+    return ret;
 }
 
 template <int OP, int BS>

@@ -349,7 +349,7 @@ def main(argv=None):
             "hipgraph": bool(args.graph), "graph_collectives": bool(tr.graph_collectives and args.graph and use_dist),
             **({"graph_note": tr.graph_note} if tr.graph_note else {}), "batched": bool(args.batched),
             "backend": (args.backend if use_dist else None),
-            "channels_last": bool(args.channels_last)}))
+            "channels_last": bool(args.channels_last), "kernel_storage": args.kernel_storage}))
         if args.export_dir:
             from .export import save_compress_parameters
             print(json.dumps(save_compress_parameters(tr.model, args.export_dir)))

@@ -100,10 +100,15 @@ def main():
                 lib.lq_batch_scale_grad_oihw(batch._handle, ptrs_o, batch.ws.data_ptr(), batch.ws.numel(), sp)
                 lib.lq_batch_scale_adam(batch._handle, 1e-4, 0.9, 0.999, 1e-7, 1, None, 0, sp)
 
+            def batched_abi_fused():            # what the trainer's nq step launches: forward, traversal, finalize + Adam
+                lib.lq_batch_forward(batch._handle, sp)
+                lib.lq_batch_scale_grad_step(batch._handle, ptrs_o, 1, batch.ws.data_ptr(), batch.ws.numel(), 1e-4, 0.9, 0.999, 1e-7, 1, None, 0, sp)
+
             row = {"config": config, "orientation": orient, "tensors": len(batch.entries), "elements": n_el,
                    "companion_only": bool(args.companion_only), "kernel_storage": args.kernel_storage,
                    "us_per_step_batched_abi": timed(batched_abi_only, args.steps, dev),
-                   "us_per_step_batched_abi_oihw": timed(batched_abi_oihw, args.steps, dev)}
+                   "us_per_step_batched_abi_oihw": timed(batched_abi_oihw, args.steps, dev),
+                   "us_per_step_batched_abi_oihw_fused_update": timed(batched_abi_fused, args.steps, dev)}
             if not args.abi_only:
                 row["us_per_step_batched_autograd"] = timed(batched_step, args.steps, dev)
                 row["us_per_step_per_tensor"] = timed(per_tensor_step, args.steps, dev)

@@ -17,6 +17,11 @@ tests)
 batch)
   bash tools/prof_batch.sh $out/batch_imagenette_channelwise imagenette:channelwise || exit 1
   bash tools/prof_batch.sh $out/batch_resnet50_channelwise resnet50:channelwise || exit 1 ;;
+batch_oihw_storage)
+  # the same two weight sets with the conv kernels STORED in OIHW order (layers.py kernel_storage, the trainer's default since
+  # round 3): plain streaming launches, no companion, dP = the weight gradient; finalize + Adam in one launch
+  bash tools/prof_batch.sh $out/batch_oihw_storage_imagenette_channelwise imagenette:channelwise --kernel-storage oihw --companion-only || exit 1
+  bash tools/prof_batch.sh $out/batch_oihw_storage_resnet50_channelwise resnet50:channelwise --kernel-storage oihw --companion-only || exit 1 ;;
 base_r02)
   ( cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT/_base_r02
     for only in imagenette:channelwise resnet50:channelwise; do
@@ -131,6 +136,7 @@ e2e)
   run --config cifar --mode nqcl --loss maxbin --value 1e-11 --rate 1e-7 --batch 128 --steps 60 --warmup 15 --batched --graph --force-dist
   run --config cifar --mode nqcl --loss maxbin --value 1e-11 --rate 1e-7 --batch 128 --steps 60 --warmup 15 --batched --graph --force-dist --ddp-mode B
   run --config imagenette --batch 64 --steps 12 --warmup 4 --batched --graph
+  run --config imagenette --batch 64 --steps 12 --warmup 4 --batched --graph --kernel-storage hwio
   run --config imagenette --batch 256 --steps 8 --warmup 3 --batched --graph
   run --config imagenette --batch 256 --steps 8 --warmup 3 --batched --graph --force-dist --ddp-mode B
   run --config resnet50 --value 1e-11 --value-coarse 1e-10 --batch 32 --steps 12 --warmup 4 --batched --graph
