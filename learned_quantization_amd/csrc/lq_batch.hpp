@@ -225,27 +225,33 @@ __global__ __launch_bounds__(kBlock) void k_batch_adam(const AdamTask* __restric
 
 // Finalize of the scale-gradient pass for every group of every tensor, and -- `ah.on` -- the Adam step of that group's scale in
 // the same launch (nothing may read or change ds in between: no loss term, no exchange of ds; the caller decides).
-// A 256-thread block serves FOUR groups of a task whose groups have at most 256 partials (a wave per group, no block barrier:
-// the summation order of the 64-thread finalize of the single-tensor entry points) or ONE group of a task with more (the
-// 256-thread finalize).  Which task and which first group a block serves comes from a per-block table (one 8-byte load
-// instead of a binary search over the prefix array: 5-7 dependent loads at the head of every block were a third of this launch).
+// A 256-thread block serves, by its entry of a per-block table (one 8-byte load instead of a binary search over the prefix
+// array: 5-7 dependent loads at the head of every block were a third of this launch):
+//   * wave form: FOUR groups of a task whose groups have at most 256 contiguous partials (a wave per group, no block barrier: the
+//     summation order of the 64-thread finalize of the single-tensor entry points);
+//   * wide form: ONE group of a task with more partials per group (the 256-thread finalize);
+//   * column form: floor(64 / inner) groups of a column traversal.  Those write one partial per (row block, column), so a
+//     group's partials sit `C` words apart and a wave per group gathers a whole line for every 4-byte word (the finalize of the
+//     ResNet-50-like set, mostly 1 x 1 kernels, read 88 MB for 20 MB of partials and took 21 us).  Here lane l of each
+//     wave walks partials of column c0 + l -- every load a contiguous run of a row of partials, the four waves taking the row
+//     blocks in turn -- and the 4 x inner totals of a group meet in LDS.  Vote sums are exact (lq_common.hpp), max|q| and counts are order-free: the outputs are those of the
+//     other forms bit for bit for lambda < 4e-4, within an ulp of the fp32 mean above.
 // The emitting thread fetches the scale's Adam state BEFORE it walks the partials, so that after the reduction only arithmetic
 // and three stores remain.
 struct FinBlock {
-    uint32_t task;        // bit 31: wide (one group per block)
+    uint32_t task;        // bit 31: wide form; bit 30: column form
     uint32_t g0;          // first group of this block within the task
 };
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict__ tasks, const FinBlock* __restrict__ blocks, uint32_t* ws,
                                                           AdamHyper ah) {
-    static_assert(OpT<OP>::kStdMerge, "wave-per-group finalize needs the DPP merge (no block barrier)");
+    using O = OpT<OP>;
+    static_assert(O::kStdMerge, "wave-per-group finalize needs the DPP merge (no block barrier)");
+    __shared__ AccW col_tot[256];
     const FinBlock fb = blocks[blockIdx.x];
-    const bool wide = (fb.task >> 31) != 0;
-    const Task& t = tasks[fb.task & 0x7fffffffu];
-    const int64_t g = (int64_t)fb.g0 + (wide ? 0 : (int64_t)(threadIdx.x >> 6));
-    if (g >= t.p.G) return;                  // wave-uniform, narrow form only (it has no block barrier)
-    const int tid = wide ? (int)threadIdx.x : (int)(threadIdx.x & 63);
+    const bool wide = (fb.task >> 31) != 0, cols = ((fb.task >> 30) & 1u) != 0;
+    const Task& t = tasks[fb.task & 0x3fffffffu];
     Params p = t.p;
     p.pa = ws + t.ws_off;
     p.pb = p.pa + t.np_pad;
@@ -261,6 +267,54 @@ __global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict
     f.o1 = nullptr;
     f.o2 = nullptr;
     f.accum = 0;
+    if (cols) {
+        // 64 / inner groups per block: lane l of every wave owns column c0 + l, wave w the row blocks w, w + 4, ... (eight
+        // partials in flight per thread: 128 row blocks are four dependent rounds, not thirty-two)
+        const int inner = (int)t.n2, gpb = 64 / inner;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int64_t g = (int64_t)fb.g0 + threadIdx.x;                       // the group this thread emits (threads < gpb)
+        const bool emits = (int)threadIdx.x < gpb && g < p.G;
+        const bool update = ah.on && t.am && emits;
+        AdamCoef c;
+        float mi = 0.f, vi = 0.f, w = 0.f;
+        if (update) {
+            c = adam_coef(ah);
+            mi = t.am[g];
+            vi = t.av[g];
+            w = t.p.s[g];
+        }
+        const int64_t col = (int64_t)fb.g0 * inner + lane, C = t.stride1;
+        AccW acc = O::template init<AccW>();
+        if (lane < gpb * inner && col < C) {
+            const int64_t n1 = t.n1;
+            for (int64_t i = wv; i < n1; i += 32) {
+                AccW v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = load_partial<O>(p, col + (i + 4 * u < n1 ? i + 4 * u : i) * C);    // clamp: loads unconditional
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i + 4 * u < n1) O::merge(acc, v[u]);
+            }
+        }
+        col_tot[threadIdx.x] = acc;
+        __syncthreads();
+        if (emits) {
+            acc = O::template init<AccW>();
+            for (int k = 0; k < inner; ++k)
+                for (int ww = 0; ww < 4; ++ww) O::merge(acc, col_tot[ww * 64 + threadIdx.x * inner + k]);      // fixed order
+            const float dsg = FinT<OP>::emit(p, f, g, acc);
+            if (update) {
+                adam_value(ah, c, dsg, mi, vi, w, t.amin);
+                t.am[g] = mi;
+                t.av[g] = vi;
+                const_cast<float*>(t.p.s)[g] = w;
+            }
+        }
+        return;
+    }
+    const int64_t g = (int64_t)fb.g0 + (wide ? 0 : (int64_t)(threadIdx.x >> 6));
+    if (g >= p.G) return;                    // wave-uniform, wave form only (it has no block barrier)
+    const int tid = wide ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     // the thread that will emit ds[g]: lane 63 of a one-wave finalize, thread 0 of the wide one
     const bool update = ah.on && t.am && tid == (wide ? 0 : 63);
     AdamCoef c;

@@ -928,15 +928,12 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
 
 template <int OP>
 static int launch_finalize(const Params& p, FinGeom f, hipStream_t st) {
-    const int64_t n = f.n1 * f.n2;
-
-    // one thread per group walks its partials one after the other: right for very many groups (throughput) or a handful of
-    // partials, a latency trap otherwise (32 partials: ~10 us) -- few groups get one wave each instead
-    if (n <= 4 || (n <= 32 && f.groups >= 2048)) {
+    const int form = finalize_form(f.groups, f.n1, f.stride1, f.n2);       // lq_traverse.hpp
+    if (form == 0) {
         hipLaunchKernelGGL((k_finalize_thread<OP>), dim3((unsigned)ceil_div(f.groups, kBlock)), dim3(kBlock), 0, st, p, f);
-    } else if (n <= 256) {
+    } else if (form == 1) {
         hipLaunchKernelGGL((k_finalize_block<OP, 64>), dim3((unsigned)f.groups), dim3(64), 0, st, p, f);
-    } else if (n <= 1024) {
+    } else if (form == 2) {
         hipLaunchKernelGGL((k_finalize_block<OP, 256>), dim3((unsigned)f.groups), dim3(256), 0, st, p, f);
     } else {
         hipLaunchKernelGGL((k_finalize_block<OP, 1024>), dim3((unsigned)f.groups), dim3(1024), 0, st, p, f);
@@ -1599,12 +1596,17 @@ static int finish_table(lq_task_table& tb, bool bwd) {
     if (e == hipSuccess) e = hipMalloc(&tb.block_task_d, bt.size() * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemcpy(tb.block_task_d, bt.data(), bt.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && bwd && gp > 0) {
-        // finalize blocks: four groups per block (a wave each) where a group has at most 256 partials, else a block per group
+        // finalize blocks: column traversals (one partial per (row block, column), a group's partials `C` words apart) get a
+        // block per floor(64 / inner) groups that reads contiguous runs of the rows of partials; otherwise four groups per block (a wave each)
+        // where a group has at most 256 partials, else a block per group
         std::vector<FinBlock> fb;
         for (size_t k = 0; k < n; ++k) {
             const Task& t = tb.h[k];
-            const bool wide = t.n1 * t.n2 > 256;
-            for (int64_t g = 0; g < t.p.G; g += wide ? 1 : 4) fb.push_back({(uint32_t)k | (wide ? 0x80000000u : 0u), (uint32_t)g});
+            const bool cols = t.mode == MODE_COL && t.n1 > 1 && t.n2 <= 64 && t.n2 == t.p.inner && t.gstride == t.n2;
+            const bool wide = !cols && t.n1 * t.n2 > 256;
+            const int64_t per = cols ? 64 / t.n2 : (wide ? 1 : 4);
+            const uint32_t flag = cols ? 0x40000000u : (wide ? 0x80000000u : 0u);
+            for (int64_t g = 0; g < t.p.G; g += per) fb.push_back({(uint32_t)k | flag, (uint32_t)g});
         }
         if (fb.size() > 0x7fffffffull) return fail(LQ_EINVAL, "lq_batch_create: too many groups");
         tb.fin_blocks = (uint32_t)fb.size();

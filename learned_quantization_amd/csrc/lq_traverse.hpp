@@ -684,14 +684,29 @@ __global__ __launch_bounds__(BS) void k_finalize_block(Params p, FinGeom f) {
 
 // One thread per group (few partials per group, possibly very many groups).
 template <int OP>
-__global__ __launch_bounds__(kBlock) void k_finalize_thread(Params p, FinGeom f) {
+__device__ __forceinline__ float finalize_thread_body(const Params& p, const FinGeom& f, int64_t g) {
     using O = OpT<OP>;
-    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= f.groups) return;
     AccW acc = O::template init<AccW>();
     for (int64_t i1 = 0; i1 < f.n1; ++i1)
         for (int64_t i2 = 0; i2 < f.n2; ++i2) O::merge(acc, load_partial<O>(p, g * f.gstride + i1 * f.stride1 + i2));
-    FinT<OP>::emit(p, f, g, acc);
+    return FinT<OP>::emit(p, f, g, acc);
+}
+
+// which form finalizes a group with this geometry: 0 = a thread, 1 = a wave (64), 2 = 256 threads, 3 = 1024 threads
+__host__ __device__ inline int finalize_form(int64_t groups, int64_t n1, int64_t stride1, int64_t n2) {
+    const int64_t n = n1 * n2;
+    // one thread per group walks its partials one after the other: right for very many groups (throughput) or a handful of
+    // partials, a latency trap otherwise (32 partials: ~10 us) -- few groups get one wave each instead
+    if (n <= 4 || (n <= 32 && groups >= 2048)) return 0;
+    (void)stride1;
+    return n <= 256 ? 1 : (n <= 1024 ? 2 : 3);
+}
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_finalize_thread(Params p, FinGeom f) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= f.groups) return;
+    finalize_thread_body<OP>(p, f, g);
 }
 
 }  // namespace lq
