@@ -165,7 +165,7 @@ def test_training_steps_agree_between_storages(dev):
     # MIOpen's weight-gradient kernels reduce with atomics (not run-to-run stable to the last ulp), and Adam's normalisation turns
     # an ulp of a near-zero gradient into a visible fraction of lr = 1e-4: parameters agree to a few percent of ONE step's size.
     # An element order mix-up anywhere would move most elements by whole steps (3e-4) or change the losses outright.
-    np.testing.assert_allclose(out["oihw"][0], out["hwio"][0], rtol=1e-5)
+    np.testing.assert_allclose(out["oihw"][0], out["hwio"][0], rtol=1e-4)     # later losses inherit the noise of the earlier updates
     for n, p0 in out["hwio"][1].items():
         np.testing.assert_allclose(out["oihw"][1][n].cpu().numpy(), p0.cpu().numpy(), rtol=1e-5, atol=5e-6, err_msg=n)
 
@@ -184,7 +184,7 @@ def test_unbatched_trainer_and_export_on_oihw_storage(dev, tmp_path):
         qi = lq.quantized_integers(layer.kernel.data, layer.nested_q_k_layer.scale.data, torch.int8).cpu().numpy()
         assert qi.shape == tuple(layer.kernel.shape)
         out[st] = (losses, qi, layer.kernel.detach().cpu().numpy())
-    np.testing.assert_allclose(out["oihw"][0], out["hwio"][0], rtol=1e-5)
+    np.testing.assert_allclose(out["oihw"][0], out["hwio"][0], rtol=1e-4)     # later losses inherit the noise of the earlier updates
     np.testing.assert_allclose(out["oihw"][2], out["hwio"][2], rtol=1e-5, atol=5e-6)      # see test_training_steps_agree_between_storages
     assert (out["oihw"][1] != out["hwio"][1]).mean() < 2e-2       # integers differ only where a weight sits within that noise of a bin edge
 

@@ -13,4 +13,5 @@ done
 mkdir -p $out/SQ
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES --output-format csv -d $out/SQ -- python3 tools/bench_weights.py --only $only --abi-only --steps 20 "$@" > $out/SQ/run.log 2> $out/SQ/err.log || exit 1
 python3 tools/prof_batch_summary.py $out $only > $out/summary.txt
+find $out -name "*kernel_trace.csv" -size +1M -delete      # the summaries are what is kept (gpurun merges at most 64 MiB back)
 cat $out/summary.txt
