@@ -21,7 +21,9 @@ import torch  # noqa: E402
 import learned_quantization_amd as lq  # noqa: E402
 
 
-def timed(fn, steps, dev):
+def timed(fn, steps, dev, reset=None):
+    if reset is not None:
+        reset()                  # every timed loop starts from the same scales and Adam state (the loops update them)
     for _ in range(10):
         fn()
     torch.cuda.synchronize(dev)
@@ -104,14 +106,22 @@ def main():
                 lib.lq_batch_forward(batch._handle, sp)
                 lib.lq_batch_scale_grad_step(batch._handle, ptrs_o, 1, batch.ws.data_ptr(), batch.ws.numel(), 1e-4, 0.9, 0.999, 1e-7, 1, None, 0, sp)
 
+            state0 = [(e.nested.scale.data.clone(), e.m.clone(), e.v.clone()) for e in batch.entries]
+
+            def reset():
+                for e, (s0, m0, v0) in zip(batch.entries, state0):
+                    e.nested.scale.data.copy_(s0)
+                    e.m.copy_(m0)
+                    e.v.copy_(v0)
+
             row = {"config": config, "orientation": orient, "tensors": len(batch.entries), "elements": n_el,
                    "companion_only": bool(args.companion_only), "kernel_storage": args.kernel_storage,
-                   "us_per_step_batched_abi": timed(batched_abi_only, args.steps, dev),
-                   "us_per_step_batched_abi_oihw": timed(batched_abi_oihw, args.steps, dev),
-                   "us_per_step_batched_abi_oihw_fused_update": timed(batched_abi_fused, args.steps, dev)}
+                   "us_per_step_batched_abi": timed(batched_abi_only, args.steps, dev, reset),
+                   "us_per_step_batched_abi_oihw": timed(batched_abi_oihw, args.steps, dev, reset),
+                   "us_per_step_batched_abi_oihw_fused_update": timed(batched_abi_fused, args.steps, dev, reset)}
             if not args.abi_only:
-                row["us_per_step_batched_autograd"] = timed(batched_step, args.steps, dev)
-                row["us_per_step_per_tensor"] = timed(per_tensor_step, args.steps, dev)
+                row["us_per_step_batched_autograd"] = timed(batched_step, args.steps, dev, reset)
+                row["us_per_step_per_tensor"] = timed(per_tensor_step, args.steps, dev, reset)
             rows.append(row)
             print(json.dumps(rows[-1]), flush=True)
             del batch, model
