@@ -267,41 +267,21 @@ __global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict
     f.o1 = nullptr;
     f.o2 = nullptr;
     f.accum = 0;
-    if (cols) {
-        // 64 / inner groups per block: lane l of every wave owns column c0 + l, wave w the row blocks w, w + 4, ... (eight
-        // partials in flight per thread: 128 row blocks are four dependent rounds, not thirty-two)
-        const int inner = (int)t.n2, gpb = 64 / inner;
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int64_t g = (int64_t)fb.g0 + threadIdx.x;                       // the group this thread emits (threads < gpb)
-        const bool emits = (int)threadIdx.x < gpb && g < p.G;
-        const bool update = ah.on && t.am && emits;
+    if (cols) {                               // finalize_cols_body (lq_traverse.hpp): 64 / n2 groups per block, whole partial rows
+        const int gpb = 64 / (int)t.n2;
+        const int64_t gp = (int64_t)fb.g0 + threadIdx.x;                      // the group this thread will hold (threads < gpb)
+        const bool update = ah.on && t.am && (int)threadIdx.x < gpb && gp < p.G;
         AdamCoef c;
         float mi = 0.f, vi = 0.f, w = 0.f;
         if (update) {
             c = adam_coef(ah);
-            mi = t.am[g];
-            vi = t.av[g];
-            w = t.p.s[g];
+            mi = t.am[gp];
+            vi = t.av[gp];
+            w = t.p.s[gp];
         }
-        const int64_t col = (int64_t)fb.g0 * inner + lane, C = t.stride1;
-        AccW acc = O::template init<AccW>();
-        if (lane < gpb * inner && col < C) {
-            const int64_t n1 = t.n1;
-            for (int64_t i = wv; i < n1; i += 32) {
-                AccW v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = load_partial<O>(p, col + (i + 4 * u < n1 ? i + 4 * u : i) * C);    // clamp: loads unconditional
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (i + 4 * u < n1) O::merge(acc, v[u]);
-            }
-        }
-        col_tot[threadIdx.x] = acc;
-        __syncthreads();
-        if (emits) {
-            acc = O::template init<AccW>();
-            for (int k = 0; k < inner; ++k)
-                for (int ww = 0; ww < 4; ++ww) O::merge(acc, col_tot[ww * 64 + threadIdx.x * inner + k]);      // fixed order
+        int64_t g;
+        AccW acc;
+        if (finalize_cols_body<OP>(p, f, (int64_t)fb.g0, col_tot, g, acc)) {
             const float dsg = FinT<OP>::emit(p, f, g, acc);
             if (update) {
                 adam_value(ah, c, dsg, mi, vi, w, t.amin);

@@ -926,10 +926,21 @@ static int launch_traverse(Plan& pl, const Params& p, hipStream_t st) {
     return check_hip("traversal launch");
 }
 
-template <int OP>
+// The column form (lq_traverse.hpp) of a single launch pays four waves per 64 columns walking n1 rows eight at a time: it wins
+// where the other forms gather megabytes of scattered words (6144 x 6144 column-wise: 8.7 -> 5.6 us; 4096 x 4096, whose 32
+// partials per group used to go to the thread form: 10.3 -> 4.8 us) and loses on small partial sets or many rows per column
+// (16384 x 1001: 4.9 -> 8.4 us, eleven dependent rounds in 16 blocks).  The multi-tensor batch uses it wherever the geometry
+// allows (its tasks share one launch, the amplified gathers add up: lq_batch.hpp).
+static bool finalize_cols_single(const FinGeom& f) {
+    return finalize_cols_ok(f.groups, f.gstride, f.n1, f.stride1, f.n2) && f.n1 <= 64 && f.n1 * f.groups * f.n2 >= 131072;
+}
+
+template <int OP, bool COLS = true>      // COLS = false: global reductions (one group) never take the column form
 static int launch_finalize(const Params& p, FinGeom f, hipStream_t st) {
     const int form = finalize_form(f.groups, f.n1, f.stride1, f.n2);       // lq_traverse.hpp
-    if (form == 0) {
+    if (COLS && finalize_cols_single(f)) {
+        if constexpr (COLS) hipLaunchKernelGGL((k_finalize_cols<OP>), dim3((unsigned)ceil_div(f.groups, 64 / f.n2)), dim3(kBlock), 0, st, p, f);
+    } else if (form == 0) {
         hipLaunchKernelGGL((k_finalize_thread<OP>), dim3((unsigned)ceil_div(f.groups, kBlock)), dim3(kBlock), 0, st, p, f);
     } else if (form == 1) {
         hipLaunchKernelGGL((k_finalize_block<OP, 64>), dim3((unsigned)f.groups), dim3(64), 0, st, p, f);
@@ -1281,7 +1292,7 @@ int lq_penalty_difference_fwd(const float* P, const float* s, float* term, void*
     if ((rc = launch_traverse<OP_DIFF_FWD>(pl, p, (hipStream_t)stream))) return rc;
     FinGeom f = global_geom(pl, outer, G, inner);
     f.o0 = term;
-    return launch_finalize<OP_DIFF_FWD>(p, f, (hipStream_t)stream);
+    return launch_finalize<OP_DIFF_FWD, false>(p, f, (hipStream_t)stream);
 }
 
 int lq_penalty_difference_bwd(const float* P, const float* s, const float* c_dev, float c_scale, float* dP, float* ds,
@@ -1602,7 +1613,7 @@ static int finish_table(lq_task_table& tb, bool bwd) {
         std::vector<FinBlock> fb;
         for (size_t k = 0; k < n; ++k) {
             const Task& t = tb.h[k];
-            const bool cols = t.mode == MODE_COL && t.n1 > 1 && t.n2 <= 64 && t.n2 == t.p.inner && t.gstride == t.n2;
+            const bool cols = finalize_cols_ok(t.p.G, t.gstride, t.n1, t.stride1, t.n2);      // the rule of the single-tensor finalize
             const bool wide = !cols && t.n1 * t.n2 > 256;
             const int64_t per = cols ? 64 / t.n2 : (wide ? 1 : 4);
             const uint32_t flag = cols ? 0x40000000u : (wide ? 0x80000000u : 0u);

@@ -702,6 +702,54 @@ __host__ __device__ inline int finalize_form(int64_t groups, int64_t n1, int64_t
     return n <= 256 ? 1 : (n <= 1024 ? 2 : 3);
 }
 
+// Column form: the partials form a matrix [n1][groups * n2] (a traversal that leaves one partial per (row block, column), or per
+// (layer, group, chunk)) and group g owns the n2 adjacent columns g*n2 ... of every row.  A wave or a thread per group would
+// gather its words `stride1` apart -- a whole line for every 4-byte word (the finalize of the ResNet-50-like batch read 88 MB for
+// 20 MB of partials; a 4096 x 4096 column-wise scale gradient spent 10 of 44 us here).  A 256-thread block instead takes
+// floor(64 / n2) groups: lane l of every wave owns column c0 + l, so every load is a contiguous run of a partial row; wave w walks
+// rows w, w + 4, ... with eight partials in flight per thread; the 4 x n2 totals of a group meet in LDS, merged in a fixed order.
+__host__ __device__ inline bool finalize_cols_ok(int64_t groups, int64_t gstride, int64_t n1, int64_t stride1, int64_t n2) {
+    return n1 > 1 && n2 >= 1 && n2 <= 64 && gstride == n2 && stride1 == groups * n2 && groups * n2 >= 256;
+}
+
+// returns true in the threads that hold a finished group (`g`, `acc`); `lds`: 256 AccW
+template <int OP>
+__device__ __forceinline__ bool finalize_cols_body(const Params& p, const FinGeom& f, int64_t g0, AccW* lds, int64_t& g, AccW& acc) {
+    using O = OpT<OP>;
+    const int inner = (int)f.n2, gpb = 64 / inner;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t col = g0 * inner + lane, C = f.stride1, n1 = f.n1;
+    acc = O::template init<AccW>();
+    if (lane < gpb * inner && col < C) {
+        for (int64_t i = wv; i < n1; i += 32) {
+            AccW v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = load_partial<O>(p, col + (i + 4 * u < n1 ? i + 4 * u : i) * C);    // clamp: loads unconditional
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + 4 * u < n1) O::merge(acc, v[u]);
+        }
+    }
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    g = g0 + threadIdx.x;
+    const bool emits = (int)threadIdx.x < gpb && g < f.groups;
+    if (emits) {
+        acc = O::template init<AccW>();
+        for (int k = 0; k < inner; ++k)
+            for (int ww = 0; ww < 4; ++ww) O::merge(acc, lds[ww * 64 + threadIdx.x * inner + k]);      // fixed order
+    }
+    return emits;
+}
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void k_finalize_cols(Params p, FinGeom f) {
+    __shared__ AccW lds[kBlock];
+    int64_t g;
+    AccW acc;
+    if (finalize_cols_body<OP>(p, f, (int64_t)blockIdx.x * (64 / (int)f.n2), lds, g, acc)) FinT<OP>::emit(p, f, g, acc);
+}
+
 template <int OP>
 __global__ __launch_bounds__(kBlock) void k_finalize_thread(Params p, FinGeom f) {
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;

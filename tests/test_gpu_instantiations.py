@@ -90,6 +90,9 @@ CASES = [
     ((3400, 5001), "rowwise", 1e-10, "rows of 5001, nt: the same off the 16-byte grid (TAIL instantiation)"),
     ((1100, 4096), "rowwise", 3e-2, "rows of 4096 below the nontemporal size: 512-thread units, default policy"),
     ((4200, 4100), "rowwise", 3e-2, "rows of 4100, nt, lambda >= 4e-4: two float4 per thread with a folded tail (K4)"),
+    # ---- k_finalize_cols<OP>: the column form of the finalize (>= 131072 partials, at most 64 row blocks; lq_kernels.hip)
+    ((4096, 4096), "columnwise", 1e-10, "column finalize of a wide column-wise matrix, K2 and K4"),
+    ((2, 2048, 4096, 1), "channelwise", 3e-2, "column finalize, groups of one column in two layers"),
 ]
 
 
@@ -130,6 +133,36 @@ def test_instantiation_parity(shape, orient, lam, what, dev, c_oracle):  # noqa:
     sshape = O.scale_shape(shape, orient)
     s = torch.rand(sshape, device=dev, generator=g) * 0.029 + 1e-3
     _check_case_c(c_oracle, P, s, dy, lam, f"{shape} {orient} lam={lam} ({what})")
+
+
+def test_penalty_terms_through_the_column_finalize(dev):  # noqa: F811
+    """MaxBin forward (k_finalize_cols<OP_MAXBIN_FWD>) and Difference backward (<OP_DIFF_BWD>) on a 1024 x 2048 column-wise
+    matrix: 64 row blocks x 2048 columns of partials -- 131072, where the column form starts -- read as whole rows
+    (custom_loss_functions.py:90-110, 172-195)."""
+    import learned_quantization_amd as lq
+    from oracle import lq_oracle_f64 as O64
+    from _bounds import assert_within_terms
+    rng = np.random.default_rng(8)
+    shape = (1024, 2048)
+    Pn = rng.normal(0, 0.05, size=shape).astype(np.float32)
+    sn = rng.uniform(1e-3, 3e-2, size=(1, 2048)).astype(np.float32)
+    desc = O.group_descriptor(shape, sn.shape)
+    Pt = _t(Pn, dev).requires_grad_(True)
+    st = _t(sn, dev).requires_grad_(True)
+    mb = lq.maxbin_term(Pt, st)
+    assert_within_terms(float(mb), O64.maxbin_term(Pn, sn, *desc), O64.term_abs("maxbin", Pn, sn, *desc), "maxbin value")
+    (mb * 0.3).backward()
+    _, ds64, ds_abs = O64.maxbin_term_grads(Pn, sn, 0.3, *desc)
+    assert_within_terms(st.grad.cpu().numpy(), ds64, ds_abs, "maxbin ds")
+    assert int(torch.count_nonzero(Pt.grad)) >= 2048, "one maximum per column at least"
+    Pt.grad = None
+    st.grad = None
+    df = lq.difference_term(Pt, st)
+    assert_within_terms(float(df), O64.difference_term(Pn, sn, *desc), O64.term_abs("difference", Pn, sn, *desc), "difference value")
+    (df * 0.7).backward()
+    dp64, ds64, ds_abs, dp_abs = O64.difference_term_grads(Pn, sn, 0.7, *desc, with_dP_abs=True)
+    assert_within_terms(Pt.grad.cpu().numpy(), dp64, dp_abs, "difference dP")
+    assert_within_terms(st.grad.cpu().numpy(), ds64, ds_abs, "difference ds")
 
 
 def _misaligned(a, dev):
