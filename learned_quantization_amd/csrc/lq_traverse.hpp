@@ -707,9 +707,23 @@ __host__ __device__ inline int finalize_form(int64_t groups, int64_t n1, int64_t
 // gather its words `stride1` apart -- a whole line for every 4-byte word (the finalize of the ResNet-50-like batch read 88 MB for
 // 20 MB of partials; a 4096 x 4096 column-wise scale gradient spent 10 of 44 us here).  A 256-thread block instead takes
 // floor(64 / n2) groups: lane l of every wave owns column c0 + l, so every load is a contiguous run of a partial row; wave w walks
-// rows w, w + 4, ... with sixteen partials in flight per thread; the 4 x n2 totals of a group meet in LDS, merged in a fixed order.
+// rows w, w + 4, ... with eight or sixteen partials in flight per thread; the 4 x n2 totals of a group meet in LDS, merged in a fixed order.
 __host__ __device__ inline bool finalize_cols_ok(int64_t groups, int64_t gstride, int64_t n1, int64_t stride1, int64_t n2) {
     return n1 > 1 && n2 >= 1 && n2 <= 64 && gstride == n2 && stride1 == groups * n2 && groups * n2 >= 64;
+}
+
+// wave `wv` of four merges rows wv, wv + 4, ... of column `col`, AH partials in flight per thread (clamped, unconditional loads)
+template <int OP, int AH>
+__device__ __forceinline__ void finalize_cols_walk(const Params& p, int64_t col, int64_t C, int64_t n1, int wv, AccW& acc) {
+    using O = OpT<OP>;
+    for (int64_t i = wv; i < n1; i += 4 * AH) {
+        AccW v[AH];
+#pragma unroll
+        for (int u = 0; u < AH; ++u) v[u] = load_partial<O>(p, col + (i + 4 * u < n1 ? i + 4 * u : i) * C);
+#pragma unroll
+        for (int u = 0; u < AH; ++u)
+            if (i + 4 * u < n1) O::merge(acc, v[u]);
+    }
 }
 
 // returns true in the threads that hold a finished group (`g`, `acc`); `lds`: 256 AccW
@@ -721,15 +735,10 @@ __device__ __forceinline__ bool finalize_cols_body(const Params& p, const FinGeo
     const int64_t col = g0 * inner + lane, C = f.stride1, n1 = f.n1;
     acc = O::template init<AccW>();
     if (lane < gpb * inner && col < C) {
-        constexpr int kAhead = 16;           // partials in flight per thread: 64 row blocks are one dependent round
-        for (int64_t i = wv; i < n1; i += 4 * kAhead) {
-            AccW v[kAhead];
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u) v[u] = load_partial<O>(p, col + (i + 4 * u < n1 ? i + 4 * u : i) * C);    // clamp: loads unconditional
-#pragma unroll
-            for (int u = 0; u < kAhead; ++u)
-                if (i + 4 * u < n1) O::merge(acc, v[u]);
-        }
+        // 64 row blocks are one dependent round with sixteen partials in flight; up to 32 row blocks eight do (the clamped
+        // loads of rows that do not exist cost issue slots and L2 reads: 1.3 us on the ResNet-18-like set)
+        if (n1 <= 32) finalize_cols_walk<OP, 8>(p, col, C, n1, wv, acc);
+        else finalize_cols_walk<OP, 16>(p, col, C, n1, wv, acc);
     }
     lds[threadIdx.x] = acc;
     __syncthreads();
