@@ -469,6 +469,41 @@ def main():
             del tr
         except Exception as e:      # never let the informational extra break the bench line
             extras["e2e_cifar_cnn_bs256_nq_channelwise_hipgraph_batched"] = {"error": repr(e)[:200]}
+        # The per-step fake-quant work of the ResNet weight sets (BASELINE configs[2], [4]; SURVEY 8d: 16 B per element) through
+        # the multi-tensor batch ABI: lq_batch_forward + lq_batch_scale_grad_step = three launches for 40 / 108 tensors, conv
+        # kernels stored in OIHW order (layers.py kernel_storage).  Same loop as tools/bench_weights.py --kernel-storage oihw.
+        try:
+            import ctypes as _ct
+
+            import learned_quantization_amd as _lq
+            _lib, _sp = _lq._hip.load(), _lq._hip.stream_ptr(dev)
+            for _cfg, _val in (("imagenette", 1e-11), ("resnet50", (1e-10, 1e-11))):
+                _lq.reset_layer_names()
+                _m = _lq.build_model(_cfg, mode="nq", value=_val, seed=42, orientation="channelwise", device=dev)
+                _b = _lq.FakeQuantBatch(_m, hwio_out=False)
+                _g = torch.Generator(device=dev).manual_seed(42)
+                _dys = [torch.empty_like(e.param.data).normal_(generator=_g) * 1e-3 for e in _b.entries]
+                _ptrs = (_ct.c_void_p * len(_dys))(*[d.data_ptr() for d in _dys])
+                _n_el = sum(e.param.numel() for e in _b.entries)
+
+                def _step():
+                    _lib.lq_batch_forward(_b._handle, _sp)
+                    _lib.lq_batch_scale_grad_step(_b._handle, _ptrs, 0, _b.ws.data_ptr(), _b.ws.numel(), 1e-4, 0.9, 0.999, 1e-7, 1, None, 0, _sp)
+                for _ in range(20):
+                    _step()
+                torch.cuda.synchronize(dev)
+                _t0 = time.perf_counter()
+                for _ in range(300):
+                    _step()
+                torch.cuda.synchronize(dev)
+                _dt = (time.perf_counter() - _t0) / 300
+                extras[f"weight_set_step_{_cfg}_channelwise_batch_abi"] = {
+                    "us_per_step": _dt * 1e6, "tensors": len(_b.entries), "elements": _n_el, "algorithmic_bytes_per_step": 16 * _n_el,
+                    "step_GBs": 16 * _n_el / _dt / 1e9, "frac_of_8TBs": 16 * _n_el / _dt / 8e12,
+                    "note": "fake-quant forward + scale gradient + scale Adam of every kernel and bias of the model in three launches"}
+                del _b, _m, _dys
+        except Exception as e:      # informational only
+            extras["weight_set_step"] = {"error": repr(e)[:200]}
 
     # HBM bytes per launch of the dominant kernel from the committed PMC passes -- only while the kernel sources still are
     # the ones that were profiled (tools/prof_pmc.sh stores their hash next to the numbers)
