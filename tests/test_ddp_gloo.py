@@ -31,10 +31,13 @@ class _FakeLayer(torch.nn.Module):
     """Same attribute surface as CustomDenseLayer (W, b, nested_q_w_layer, nested_q_b_layer); the fake-quant op is
     replaced by an oracle-backed autograd function so the test runs without a GPU."""
 
-    def __init__(self, lam):
+    def __init__(self, lam, permuted=False):
         super().__init__()
         g = torch.Generator().manual_seed(0)
-        self.W = torch.nn.Parameter(torch.randn(12, 5, generator=g) * 0.05)
+        w = torch.randn(12, 5, generator=g) * 0.05
+        if permuted:            # same shape and values, memory in (5, 12) order: what kernel_storage="oihw" does to a conv kernel
+            w = w.t().contiguous().t()
+        self.W = torch.nn.Parameter(w)
         self.b = torch.nn.Parameter(torch.randn(5, generator=g) * 0.05)
         self.nested_q_w_layer = _FakeNested((12, 1), lam)
         self.nested_q_b_layer = _FakeNested((1,), lam)
@@ -65,20 +68,22 @@ def _oracle_scale_grad(P, s, dy, lam):
     return torch.from_numpy(O.nq_backward(P.numpy(), s.numpy(), lam, dy.numpy())[1])
 
 
-def _worker(rank, world, port, mode, out_dir):
+def _worker(rank, world, port, mode, out_dir, permuted=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from learned_quantization_amd.ddp import DataParallel
     lam = 2e-2
-    model = _FakeLayer(lam)
+    model = _FakeLayer(lam, permuted)
+    assert model.W.is_contiguous() != permuted
     if rank == 1:   # replicas start different on purpose: the wrapper must broadcast rank 0's
         with torch.no_grad():
             model.W.add_(1.0)
     # mode A with tiny sub-buckets: every parameter is its own overlapped all-reduce; mode B: one bucket
     dp = DataParallel(model, mode=mode, scale_grad_fn=_oracle_scale_grad, bucket_mb=(1e-5 if mode == "A" else 25.0))
     assert len(dp._ranges) == (4 if mode == "A" else 1)       # views are padded to 64 floats: W, b and both scales
+    assert model.W.grad.stride() == model.W.stride(), "the bucket view carries the parameter's strides"
     g = torch.Generator().manual_seed(123)
     X = torch.randn(8, 12, generator=g)
     Y = torch.randn(8, 5, generator=g)
@@ -89,15 +94,19 @@ def _worker(rank, world, port, mode, out_dir):
     dp.sync_gradients()
     res = {n: p.grad.clone() for n, p in model.named_parameters()}
     res["W_param"] = model.W.detach().clone()
+    assert model.W.grad.stride() == model.W.stride()
+    res = {k: v.contiguous() for k, v in res.items()}
     torch.save(res, os.path.join(out_dir, f"rank{rank}_{mode}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["A", "B"])
-def test_data_parallel_two_ranks(tmp_path, mode):
+@pytest.mark.parametrize("mode,permuted", [("A", False), ("B", False), ("A", True), ("B", True)])
+def test_data_parallel_two_ranks(tmp_path, mode, permuted):
+    """``permuted``: W is a dense permuted view (the memory layout of a conv kernel stored in OIHW order): broadcast, bucket
+    views and the exchange must treat it index by index like the contiguous parameter."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, mode, str(tmp_path), permuted), nprocs=2, join=True)
     r0 = torch.load(tmp_path / f"rank0_{mode}.pt")
     r1 = torch.load(tmp_path / f"rank1_{mode}.pt")
     assert torch.equal(r0["W_param"], r1["W_param"])                 # broadcast happened
@@ -209,3 +218,10 @@ def test_grad_bucket_single_process():
     assert torch.all(b.flat[64:69] == 7) and ps[1].grad.data_ptr() == b.views[1].data_ptr()
     b.zero_()
     assert torch.count_nonzero(b.flat) == 0
+    # a dense permuted parameter (conv kernel shaped HWIO, stored OIHW): the view has the parameter's strides, so that gradient
+    # and parameter are read with one memory-order descriptor
+    k = torch.nn.Parameter(torch.randn(4, 3, 2, 2).permute(2, 3, 1, 0))
+    b2 = GradBucket([ps[0], k])
+    assert k.grad.shape == k.shape and k.grad.stride() == k.stride() and not k.grad.is_contiguous()
+    (k * torch.arange(48.0).view(4, 3, 2, 2).permute(2, 3, 1, 0)).sum().backward()
+    assert torch.equal(b2.flat[64:112], torch.arange(48.0)), "bucket memory in the parameter's memory order"
