@@ -22,10 +22,11 @@ def main():
     which = sys.argv[2] if len(sys.argv) > 2 else "fwd"
     dev = torch.device("cuda:0")
     lam = 1e-11
-    model = lq.build_model(config, mode="nq", value=(1e-10, lam) if config == "resnet50" else lam, seed=42, orientation=orient, device=dev, kernel_storage="hwio")
+    model = lq.build_model(config, mode="nq", value=(1e-10, lam) if config == "resnet50" else lam, seed=42, orientation=orient, device=dev,
+                           kernel_storage=os.environ.get("LQ_TIMELINE_STORAGE", "hwio"))     # oihw: the trainer's default (plain launches)
     batch = lq.FakeQuantBatch(model, hwio_out=os.environ.get('LQ_TIMELINE_HWIO_OUT', '1') != '0')
     g = torch.Generator(device=dev).manual_seed(42)
-    dys = [torch.randn(e.shape, device=dev, generator=g) * 1e-3 for e in batch.entries]
+    dys = [torch.empty_like(e.param.data).normal_(generator=g) * 1e-3 for e in batch.entries]
     dys_o = [d.permute(3, 2, 0, 1).contiguous() if e.out_oihw is not None else d for e, d in zip(batch.entries, dys)]
     lib = lq._hip.load()
     lib.lq_dev_set_trace.restype = ctypes.c_int

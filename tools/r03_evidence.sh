@@ -92,6 +92,14 @@ timeline)
     done
   done
   LQ_TIMELINE_HWIO_OUT=0 timeout -k 10 200 python3 tools/block_timeline.py imagenette:channelwise fwd > $out/timeline_imagenette_channelwise_fwd_companion_only.txt 2>> $out/timeline.err || exit 1
+  # conv kernels stored OIHW (the trainer's default): plain streaming launches
+  for c in imagenette:channelwise resnet50:channelwise; do
+    for w in fwd bwd; do
+      n=$(echo "timeline_oihw_storage_${c}_$w" | tr ':' '_')
+      LQ_TIMELINE_STORAGE=oihw LQ_TIMELINE_HWIO_OUT=0 timeout -k 10 200 python3 tools/block_timeline.py $c $w > $out/$n.txt 2> $out/$n.err || { tail -n 5 $out/$n.err; exit 1; }
+      head -n 2 $out/$n.txt
+    done
+  done
   unset LQ_HIP_LIB ;;
 batchtests)
   timeout -k 10 900 python3 -m pytest tests/test_gpu_batch.py tests/test_gpu_harness.py -q -m gpu -x -p no:cacheprovider > $out/pytest_batch.log 2>&1; rc=$?
