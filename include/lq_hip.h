@@ -163,8 +163,10 @@ int lq_q_absmax_over_axis(const float* P, const float* s, float* result,
  *                          overrides the descriptors' dy -- the upstream gradients move every step
  *   lq_batch_scale_adam  = lq_scale_adam_step(_dev) of every scale with Adam state in ONE launch
  *   lq_batch_scale_grad_step = the two above in the two launches of the first
- * Results are bit-identical to the single-tensor entry points for tensors below 4 M elements (same device
- * code and reduction geometry); larger tensors differ only by fp32 summation order (~1e-7 relative).
+ * q, out, max|q| and vote counts are bit-identical to the single-tensor entry points, and so is ds for lambda < 4e-4 (every
+ * published threshold: the vote sums are exact in float64, any traversal and finalize order gives the same bits); for larger
+ * lambda the float64 summation order of the traversal (tensors from 4 M elements) or of the finalize form may differ, which
+ * reaches the fp32 result only when the mean sits on a rounding boundary.
  * lq_batch_create/destroy allocate/free the table (hipMalloc; not stream-ordered, never inside a capture);
  * the other calls only enqueue.  lambda = NaN marks an STE-only tensor (custom_loss_terms variant).        */
 typedef struct lq_tensor_desc {

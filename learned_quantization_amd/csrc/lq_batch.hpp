@@ -9,8 +9,8 @@ namespace lq {
 // ------------------------------------------------------------------------------------------
 //  Multi-tensor batch (SURVEY f-4): the 4 / 12 / 40 weight-sized tensors a training step fake-quantises
 //  are latency-bound one by one (each launch costs more than its work).  A batch is a device-resident
-//  table of tasks; ONE launch covers every tensor's traversal (each 256-thread block finds its task by
-//  binary search over a contiguous block-prefix array) and ONE launch finalizes every group of every tensor.
+//  table of tasks; ONE launch covers every tensor's traversal (each 256-thread block finds its task in a per-block
+//  table) and ONE launch finalizes every group of every tensor -- and can apply the scales' Adam step (k_batch_finalize_t).
 //  The per-tensor code is the single-tensor traversal bodies, or -- conv kernels with an OIHW companion -- the LDS tile
 //  of lq_conv_tile.hpp; forward outputs, max|q| and vote counts are bit-identical to the single-tensor entry points by
 //  construction, the vote sums because they are exact (lq_common.hpp, Acc).
