@@ -112,8 +112,12 @@ def test_one_rank_rccl_rehearsal():
     for name in ("nqcl_B_batched", "nqcl_A_batched"):
         assert res[name]["max_param_diff"] == 0.0, (name, res[name])
         assert res[name]["losses"] == res[name]["ref_losses"], (name, res[name])
-    r18 = res["B_batched_regularized_resnet18"]       # identical up to the run-to-run spread of the convolutions themselves
-    assert r18["max_param_diff"] <= 4.0 * r18["ref_self_diff"], r18
+    # identical up to the run-to-run spread of the convolutions themselves (MIOpen's weight gradients reduce with atomics): Adam
+    # turns an ulp of a near-zero gradient into up to lr = 1e-4 per step, so single elements may differ by two steps' worth
+    # whichever two runs are compared; on average the parameters agree as well as two identical runs do
+    r18 = res["B_batched_regularized_resnet18"]
+    assert r18["max_param_diff"] <= max(4.0 * r18["ref_self_diff"], 2.5e-4), r18
+    assert r18["mean_param_diff"] <= 4.0 * r18["ref_self_mean_diff"] + 1e-9, r18
     np.testing.assert_allclose(r18["losses"], r18["ref_losses"], rtol=1e-4)
     for name in ("graph_split_A_batched", "graph_split_B_batched", "graph_split_A"):
         assert "error" not in res[name], (name, res[name])

@@ -44,6 +44,10 @@ def diff(a, b):
     return max(float((a[k] - b[k]).abs().max()) for k in a)
 
 
+def mean_diff(a, b):
+    return sum(float((a[k] - b[k]).abs().sum()) for k in a) / sum(a[k].numel() for k in a)
+
+
 out = {}
 if not ONLY_CAPTURED_COLLECTIVES:
     _, ref_losses, ref = run()                           # plain single-process trainer (no DataParallel)
@@ -81,7 +85,8 @@ if not ONLY_CAPTURED_COLLECTIVES:
     assert tr0.regularized, "the ResNet-18-like net carries l2 regularisers"
     _, _, p0b = run(setup=res18, data=d18, steps=2, batched=True)       # MIOpen's weight-gradient kernels may not be run-to-run stable
     tr, l1, p1 = run(setup=res18, data=d18, steps=2, ddp_mode="B", batched=True, force_collectives=True)
-    out["B_batched_regularized_resnet18"] = {"max_param_diff": diff(p1, p0), "ref_self_diff": diff(p0b, p0), "losses": l1, "ref_losses": l0}
+    out["B_batched_regularized_resnet18"] = {"max_param_diff": diff(p1, p0), "ref_self_diff": diff(p0b, p0), "losses": l1, "ref_losses": l0,
+                                             "mean_param_diff": mean_diff(p1, p0), "ref_self_mean_diff": mean_diff(p0b, p0)}
 # graphed steps against their eager data-parallel counterparts
 graphed = {"graph_split_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True, graph_collectives=False),
            "graph_split_B_batched": dict(ddp_mode="B", batched=True, force_collectives=True, graph_collectives=False),
