@@ -151,6 +151,15 @@ def test_batch_and_layers_give_the_same_numbers_for_either_storage(dev, orient):
                 f"{st}: ds of the batch == the single-tensor op on the gradient that arrived"
 
 
+def _params_agree(a, b, steps, name, lr=1e-4):
+    """Two runs of the same training differ by MIOpen's run-to-run noise (its weight gradients reduce with atomics), and Adam turns
+    an ulp of a near-zero gradient into up to `lr` per step: single elements may be off by `steps` whole steps, the average
+    element by far less than a hundredth of one.  An element-order mix-up moves most elements by whole steps."""
+    d = (a.double() - b.double()).abs()
+    assert float(d.max()) <= steps * lr * 1.25, f"{name}: max difference {float(d.max())}"
+    assert float(d.mean()) <= lr / 100, f"{name}: mean difference {float(d.mean())}"
+
+
 def test_training_steps_agree_between_storages(dev):
     """Three steps of the batched trainer on the CIFAR CNN, `nqcl` (nested quantization + MaxBin loss term): same losses and
     parameters for either storage (the convolutions and the optimizer see the same numbers; only addresses differ)."""
@@ -162,12 +171,9 @@ def test_training_steps_agree_between_storages(dev):
         tr.model.eval()
         losses = [float(tr.step(x, y).detach()) for _ in range(3)]
         out[st] = (losses, {n: p.detach().clone() for n, p in tr.model.named_parameters()})
-    # MIOpen's weight-gradient kernels reduce with atomics (not run-to-run stable to the last ulp), and Adam's normalisation turns
-    # an ulp of a near-zero gradient into a visible fraction of lr = 1e-4: parameters agree to a few percent of ONE step's size.
-    # An element order mix-up anywhere would move most elements by whole steps (3e-4) or change the losses outright.
     np.testing.assert_allclose(out["oihw"][0], out["hwio"][0], rtol=1e-4)     # later losses inherit the noise of the earlier updates
     for n, p0 in out["hwio"][1].items():
-        np.testing.assert_allclose(out["oihw"][1][n].cpu().numpy(), p0.cpu().numpy(), rtol=1e-5, atol=5e-6, err_msg=n)
+        _params_agree(out["oihw"][1][n], p0, 3, n)
 
 
 def test_unbatched_trainer_and_export_on_oihw_storage(dev, tmp_path):
@@ -185,7 +191,7 @@ def test_unbatched_trainer_and_export_on_oihw_storage(dev, tmp_path):
         assert qi.shape == tuple(layer.kernel.shape)
         out[st] = (losses, qi, layer.kernel.detach().cpu().numpy())
     np.testing.assert_allclose(out["oihw"][0], out["hwio"][0], rtol=1e-4)     # later losses inherit the noise of the earlier updates
-    np.testing.assert_allclose(out["oihw"][2], out["hwio"][2], rtol=1e-5, atol=5e-6)      # see test_training_steps_agree_between_storages
+    _params_agree(torch.from_numpy(out["oihw"][2]), torch.from_numpy(out["hwio"][2]), 2, "first conv kernel")
     assert (out["oihw"][1] != out["hwio"][1]).mean() < 2e-2       # integers differ only where a weight sits within that noise of a bin edge
 
 
