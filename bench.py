@@ -152,10 +152,14 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        # a bounded collective timeout: ranks that ever disagree about the sequence of collectives abort within minutes with
+        # RCCL's own message instead of hanging until the driver's limit
+        tmo = datetime.timedelta(minutes=5)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
 
     from learned_quantization_amd import _hip
     lib = _hip.load()
@@ -302,25 +306,47 @@ def main():
 
     graphs = None
     if want_graph:
+        from learned_quantization_amd.ddp import CaptureRefused, capture_with_agreement, control_group
         S = max(1, args.graph_steps)
-        try:
-            if use_dist:
-                # two eager steps first: RCCL sets up its channels, buffers and kernels at the first collective of a communicator
-                # (allocations and IPC exchanges that must not happen inside a capture)
-                for i in range(2):
-                    step(i)
-                fence()
+        ctl = control_group() if use_dist else None        # gloo side group: host-side agreement on the outcome of the capture
+        if use_dist:
+            # two eager steps first: RCCL sets up its channels, buffers and kernels at the first collective of a communicator
+            # (allocations and IPC exchanges that must not happen inside a capture)
+            for i in range(2):
+                step(i)
+            fence()
+        torch.cuda.synchronize(dev)
+        captured = {}
+
+        def attempt():
+            try:
+                captured[S] = capture(S)
+                for r in {args.warmup % S, args.steps % S} - {0}:
+                    captured[r] = capture(r)               # the remainder of a loop whose length is not a multiple of S
+                torch.cuda.synchronize(dev)
+            except _hip.LQError:
+                raise                                      # an error of the path itself, not a refused capture
+            except RuntimeError as e:
+                raise CaptureRefused(f"{e!r}"[:300]) from e
+
+        def health():
+            import datetime
+            t = torch.ones(1, device=dev)
+            dist.all_reduce(t, async_op=True).wait(timeout=datetime.timedelta(seconds=60))
             torch.cuda.synchronize(dev)
-            graphs = {S: capture(S)}
-            for r in {args.warmup % S, args.steps % S} - {0}:
-                graphs[r] = capture(r)                     # the remainder of a loop whose length is not a multiple of S
-            torch.cuda.synchronize(dev)
-        except Exception as e:                             # a stack that cannot capture the collective: the eager form runs
+            if int(t.item()) != world:
+                raise RuntimeError(f"health check: all-reduce over {world} ranks returned {float(t)}")
+
+        # every rank keeps its graphs, or every rank drops them for the eager sync exchange, or every rank stops: a rank that
+        # fell back on its own would issue another sequence of collectives than the others and hang them
+        if capture_with_agreement(attempt, ctl, health_check=health if use_dist else None):
+            graphs = captured
+        else:
             if args.graph or args.exchange == "graph":
-                raise
+                raise SystemExit("the step graph (with its all-reduce) could not be captured on every rank; asked for explicitly")
             graphs = None
             exchange_form = "sync"
-            graph_note = f"graph capture failed ({e!r}"[:200] + "): eager sync exchange"
+            graph_note = "graph capture was refused on at least one rank: eager sync exchange on every rank"
     if exchange_form == "graph" and graphs is None:
         exchange_form = "sync"
 

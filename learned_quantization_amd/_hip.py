@@ -17,8 +17,20 @@ import torch
 from .descriptor import memory_order
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LQ_HIP_LIB overrides the library path (development: experiment builds of the same ABI)
-LIB_PATH = os.environ.get("LQ_HIP_LIB") or os.path.join(_HERE, "csrc", "liblq_hip.so")
+# The product loads THE in-tree library and reads no environment variable.  Development builds of the same ABI (tuning knobs,
+# experiments) are selected explicitly with ``use_library(path)`` before the first call -- only tools/ does that (tools/_devlib.py).
+LIB_PATH = os.path.join(_HERE, "csrc", "liblq_hip.so")
+_lib: Optional[ctypes.CDLL] = None
+_pending: Optional[ctypes.CDLL] = None
+_selftest_error: Optional[str] = None
+
+
+def use_library(path: str) -> None:
+    """Development only: load another build of the same C ABI instead of the shipped one.  Must be called before the first op."""
+    global LIB_PATH
+    if _lib is not None or _pending is not None:
+        raise RuntimeError("use_library() must be called before the library is loaded")
+    LIB_PATH = os.path.abspath(path)
 
 LQ_Q_NONE, LQ_Q_F32, LQ_Q_I32, LQ_Q_I8 = 0, 1, 2, 3
 LQ_ADAM_KERAS, LQ_ADAM_TORCH = 0, 1
@@ -86,7 +98,6 @@ SIGNATURES.update({
     "lq_profile_events": (_c_int, [_c_p, _c_p]),
 })
 
-_lib: Optional[ctypes.CDLL] = None
 _lock = threading.RLock()
 
 
@@ -129,19 +140,12 @@ def load() -> ctypes.CDLL:
         return lib                        # test deferred (no GPU visible yet, or a stream capture is running): next call retries
 
 
-_pending: Optional[ctypes.CDLL] = None
-_selftest_error: Optional[str] = None
-
-
 def _device_selftest(lib) -> bool:
     """On the first load with a GPU present: 2^24 random operand pairs through each of the two fast division forms
     against the IEEE '/' ON THIS DEVICE.  The bit-exact-integer guarantee rests on them; a compiler or hardware
-    combination that ever disagrees must fail loudly, not quantise differently.  Returns True when the test ran and passed
-    (or was waived with LQ_SKIP_SELFTEST=1), False when it has to be deferred; raises -- now and on every later load() --
-    when it failed."""
+    combination that ever disagrees must fail loudly, not quantise differently.  Returns True when the test ran and passed,
+    False when it has to be deferred; raises -- now and on every later load() -- when it failed."""
     global _selftest_error
-    if os.environ.get("LQ_SKIP_SELFTEST") == "1":
-        return True
     if not torch.cuda.is_available():
         return False
     if torch.cuda.is_current_stream_capturing():

@@ -156,6 +156,11 @@ class FakeQuantBatch:
             fn = lib.lq_batch_scale_grad_oihw if oihw else lib.lq_batch_scale_grad
             _hip.check(fn(self._handle, self._ptrs, _hip.ptr(self.ws), self.ws.numel(), sp), "lq_batch_scale_grad")
             return
+        if opt._applied:
+            # the finalize of a scale-gradient pass applies Adam: a second pass before step() (gradient accumulation, a retried
+            # backward) would update the scales twice and the weights once
+            raise RuntimeError("FakeQuantBatch: the fused scale update of this step has already been applied; call the optimizer's "
+                               "step() first, or build BatchedScaleAdam(fused=False) (fused=True excludes gradient accumulation)")
         step, step_dev = opt._advance()
         h = self.hyper
         md = {"keras": _hip.LQ_ADAM_KERAS, "torch": _hip.LQ_ADAM_TORCH}[h["mode"]]
@@ -300,7 +305,8 @@ class BatchedScaleAdam:
         """``fused``: the batch's scale-gradient finalize applies this optimizer's step in the same launch
         (lq_batch_scale_grad_step) and ``step()`` only acknowledges it.  For training steps in which nothing reads or changes the
         scale gradients between backward and ``step()`` -- no loss term, no exchange of ds (single process, or exact data-parallel
-        mode B where ds is computed after the exchange); every tensor must be a nested-quantization one."""
+        mode B where ds is computed after the exchange); every tensor must be a nested-quantization one.  Exactly ONE
+        scale-gradient pass per ``step()``: a second one raises (it would apply Adam to the scales twice) -- no gradient accumulation."""
         self.batch = batch
         self.capturable = capturable
         self._applied = False

@@ -33,6 +33,83 @@ import torch.distributed as dist
 from .descriptor import memory_order
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Collective control decisions.  Which FORM of the step a rank runs (one hipGraph holding the RCCL all-reduce, or graph / eager
+# all-reduce / graph, or plain eager launches) decides the SEQUENCE of collectives it issues; if one rank fell back on its own
+# because its capture failed while the others kept the captured form, the ranks would wait for each other forever.  So the
+# outcome of every capture attempt is agreed on over a host-side (gloo) group before anybody proceeds: all ranks keep their
+# graphs, or all drop them, or -- on an error that is not a refused capture -- all raise.
+CAPTURED, REFUSED, FATAL = 1, 0, -1
+
+
+class CaptureRefused(RuntimeError):
+    """The stack refused to record the collective into a hipGraph (raised by the attempt passed to ``capture_with_agreement``)."""
+
+
+_control_groups = {}
+
+
+def control_group(group=None):
+    """A gloo group over the ranks of ``group`` for host-side agreement (None while torch.distributed is not initialised; the
+    group itself when it already is gloo).  COLLECTIVE on first use: every rank must call it at the same point of the program
+    (Trainer.__init__, bench.py right after init_process_group)."""
+    if not dist.is_initialized():
+        return None
+    if dist.get_backend(group) == "gloo":
+        return group if group is not None else dist.group.WORLD
+    key = id(group) if group is not None else None
+    if key not in _control_groups:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        _control_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _control_groups[key]
+
+
+def agree(code: int, ctl_group) -> int:
+    """MIN over the ranks of an integer decision code: every rank returns the same value."""
+    if ctl_group is None:
+        return code
+    t = torch.tensor([int(code)], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=ctl_group)
+    return int(t.item())
+
+
+def capture_with_agreement(attempt: Callable[[], None], ctl_group, health_check: Optional[Callable[[], None]] = None) -> bool:
+    """Runs ``attempt()`` (this rank's capture) and agrees with the other ranks on what happened.
+
+    True: every rank captured -- keep the graphs.  False: at least one rank's capture was refused (``CaptureRefused``) -- EVERY rank
+    must drop whatever it captured and take the fallback form; before returning False ``health_check()`` (an eager collective on
+    the product communicator with a bounded wait) must pass on every rank, else all raise: a communicator that a failed capture left
+    unusable is a reason to stop with a message, not to hang in the next all-reduce.  Any other exception in ``attempt`` is an error
+    of the step itself (argument validation, shapes): it is re-raised on the rank that saw it and the other ranks raise too."""
+    err = None
+    try:
+        attempt()
+        code = CAPTURED
+    except CaptureRefused as e:
+        code, err = REFUSED, e
+    except BaseException as e:              # noqa: BLE001 -- reported to the other ranks first, then re-raised
+        code, err = FATAL, e
+    agreed = agree(code, ctl_group)
+    if code == FATAL:
+        raise err
+    if agreed == FATAL:
+        raise RuntimeError("capture_with_agreement: another rank failed while recording the step (not a refused capture); stopping "
+                           "on every rank")
+    if agreed == CAPTURED:
+        return True
+    ok = CAPTURED
+    herr = None
+    if health_check is not None:
+        try:
+            health_check()
+        except BaseException as e:          # noqa: BLE001
+            ok, herr = FATAL, e
+    if agree(ok, ctl_group) != CAPTURED:
+        raise RuntimeError("the collective could not be recorded into a hipGraph on every rank and the communicator does not answer "
+                           "afterwards; rerun with --no-graph-collectives (train) / --exchange sync (bench)") from (herr or err)
+    return False
+
+
 class GradBucket:
     """Flat fp32 bucket over a fixed parameter list; grads become views into it.  Every view starts on a 256-byte
     boundary (the kernels' float4 paths need 16-byte aligned gradient buffers, lq_hip.h; one-element scales would
@@ -269,6 +346,19 @@ class DataParallel:
                 h.wait()
             self._handles = []
         self._synced = True
+
+    def health_check(self, seconds: float = 60.0):
+        """One eager all-reduce on the product communicator with a bounded wait (after a refused capture)."""
+        if not self._collectives:
+            return
+        import datetime
+        t = torch.ones(1, device=self.bucket.flat.device)
+        h = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        h.wait(timeout=datetime.timedelta(seconds=seconds))
+        if self.bucket.flat.is_cuda:
+            torch.cuda.synchronize(self.bucket.flat.device)
+        if int(t.item()) != self.world:
+            raise RuntimeError(f"health check: all-reduce over {self.world} ranks returned {float(t)}")
 
     def recompute_scale_grads(self):
         """Mode B: ds from the all-reduced P.grad, which IS the global-batch dy (dP == dy, custom_layers.py:118)."""

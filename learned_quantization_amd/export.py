@@ -27,20 +27,26 @@ from . import ops
 from .layers import CustomDenseLayer, _ConvBase
 
 
+def _host(t: torch.Tensor) -> np.ndarray:
+    """C-contiguous host array in the tensor's LOGICAL index order.  A conv kernel stored in OIHW order behind its HWIO shape comes
+    back from ``.cpu().numpy()`` with permuted strides -- a 1x1 kernel even F-contiguous, which numpy pickles in Fortran byte order:
+    the bytes of weights.npy (and the compressed size in file_sizes.log) would then depend on the storage."""
+    return np.ascontiguousarray(t.detach().cpu().numpy())
+
+
 def quantized_state(model: torch.nn.Module) -> Dict[str, np.ndarray]:
     weights: Dict[str, np.ndarray] = {}
+
+    def q(param, nested):
+        return _host(ops.quantized_integers(param.data, nested.scale.data, torch.int8))
     for layer in model.modules():
         if isinstance(layer, _ConvBase):
-            weights[layer.name + "/W"] = ops.quantized_integers(layer.kernel.data, layer.nested_q_k_layer.scale.data,
-                                                                torch.int8).cpu().numpy()
+            weights[layer.name + "/W"] = q(layer.kernel, layer.nested_q_k_layer)
             if layer._has_bias:
-                weights[layer.name + "/b"] = ops.quantized_integers(layer.b.data, layer.nested_q_b_layer.scale.data,
-                                                                    torch.int8).cpu().numpy()
+                weights[layer.name + "/b"] = q(layer.b, layer.nested_q_b_layer)
         elif isinstance(layer, CustomDenseLayer):
-            weights[layer.name + "/W"] = ops.quantized_integers(layer.W.data, layer.nested_q_w_layer.scale.data,
-                                                                torch.int8).cpu().numpy()
-            weights[layer.name + "/b"] = ops.quantized_integers(layer.b.data, layer.nested_q_b_layer.scale.data,
-                                                                torch.int8).cpu().numpy()
+            weights[layer.name + "/W"] = q(layer.W, layer.nested_q_w_layer)
+            weights[layer.name + "/b"] = q(layer.b, layer.nested_q_b_layer)
     return weights
 
 
@@ -50,7 +56,7 @@ def scale_state(model: torch.nn.Module) -> Dict[str, np.ndarray]:
         for attr, tag in (("nested_q_k_layer", "/W_scale"), ("nested_q_w_layer", "/W_scale"), ("nested_q_b_layer", "/b_scale")):
             nested = getattr(layer, attr, None)
             if nested is not None and getattr(nested, "scale", None) is not None and hasattr(layer, "name"):
-                out[layer.name + tag] = nested.scale.detach().cpu().numpy()
+                out[layer.name + tag] = _host(nested.scale)
     return out
 
 
@@ -61,9 +67,9 @@ def save_compress_parameters(model: torch.nn.Module, log_dir: str) -> Dict[str, 
     weights = quantized_state(model)
     for name, layer in model.named_modules():
         if isinstance(layer, (torch.nn.Conv2d, torch.nn.Linear)):            # log_scripts.py:80-82
-            weights[name + "/W"] = layer.weight.detach().cpu().numpy()
+            weights[name + "/W"] = _host(layer.weight)
             if layer.bias is not None:
-                weights[name + "/b"] = layer.bias.detach().cpu().numpy()
+                weights[name + "/b"] = _host(layer.bias)
     np.save(weights_path, weights)                                             # pickled dict, like the reference
     zip_file_path = os.path.join(log_dir, "weights.zip")
     with zipfile.ZipFile(zip_file_path, "w", compression=zipfile.ZIP_DEFLATED) as zipf:

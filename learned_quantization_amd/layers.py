@@ -241,12 +241,18 @@ class CustomDenseLayer(_HostLayer):
     def _regularized(self):
         return (self.W, self.b)
 
+    def quantized_parameters(self):
+        """(qW, qb) of this call: what FakeQuantBatch.quantize_all() left for the layer (one launch for all tensors, consumed
+        once), else the nested layers' own ops (NQ-L:265-266)."""
+        pre, self._q_pre = getattr(self, "_q_pre", None), None
+        if pre is not None:
+            return pre[0], pre[1]
+        return self.nested_q_w_layer(self.W), self.nested_q_b_layer(self.b)
+
     def call(self, inputs):
         if not self.built:
             self.build(tuple(inputs.shape), device=inputs.device)
-        pre, self._q_pre = getattr(self, "_q_pre", None), None   # set by FakeQuantBatch.quantize_all() (one launch for all)
-        qw = pre[0] if pre is not None else self.nested_q_w_layer(self.W)     # NQ-L:265
-        qb = pre[1] if pre is not None else self.nested_q_b_layer(self.b)     # NQ-L:266
+        qw, qb = self.quantized_parameters()
         return torch.add(torch.matmul(inputs, qw), qb)           # NQ-L:268
 
     forward = call
@@ -348,11 +354,11 @@ class _ConvBase(_HostLayer):
     def _regularized(self):
         return (self.kernel, self.b) if self._has_bias else (self.kernel,)
 
-    def call(self, inputs):
-        if not self.built:
-            self.build(tuple(inputs.shape), device=inputs.device)
-        pre, self._q_pre = getattr(self, "_q_pre", None), None   # set by FakeQuantBatch.quantize_all() (one launch for all)
-        x = inputs.permute(0, 3, 1, 2) if self.data_format == "NHWC" else inputs
+    def quantized_parameters(self):
+        """(w, qb) of this call: ``w`` is the fake-quantised kernel as the OIHW-shaped tensor the convolution consumes (NQ-L:340),
+        ``qb`` the fake-quantised bias (NQ-L:341; None without one) -- from FakeQuantBatch.quantize_all() when it ran (one launch
+        for all tensors, consumed once), else from the nested layers' own ops."""
+        pre, self._q_pre = getattr(self, "_q_pre", None), None
         nested = self.nested_q_k_layer
         if pre is not None and len(pre) > 2 and pre[2] is not None:
             w = pre[2]                                   # the batch emitted the OIHW companion with the same launch
@@ -368,6 +374,15 @@ class _ConvBase(_HostLayer):
             # NQ-L:340; HWIO -> OIHW view -- contiguous when the kernel is stored "oihw": MIOpen takes it as it is and its
             # weight gradient comes back with the parameter's own strides
             w = nested(self.kernel).permute(3, 2, 0, 1)
+        if not self._has_bias:
+            return w, None
+        return w, (pre[1] if pre is not None else self.nested_q_b_layer(self.b))
+
+    def call(self, inputs):
+        if not self.built:
+            self.build(tuple(inputs.shape), device=inputs.device)
+        x = inputs.permute(0, 3, 1, 2) if self.data_format == "NHWC" else inputs
+        w, qb = self.quantized_parameters()
         if self.padding == "SAME":
             ph = _same_padding(x.shape[-2], self.kernel_size[0], self.strides[0])
             pw = _same_padding(x.shape[-1], self.kernel_size[1], self.strides[1])
@@ -377,8 +392,7 @@ class _ConvBase(_HostLayer):
                 y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), w, None, self.strides, 0)
         else:
             y = F.conv2d(x, w, None, self.strides, 0)                                      # NQ-L:343-348
-        if self._has_bias:
-            qb = pre[1] if pre is not None else self.nested_q_b_layer(self.b)              # NQ-L:341
+        if qb is not None:
             y = torch.add(y, qb.view(1, -1, 1, 1))                                         # NQ-L:350
         return y.permute(0, 2, 3, 1) if self.data_format == "NHWC" else y
 

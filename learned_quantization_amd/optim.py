@@ -34,6 +34,21 @@ def apply_constraints(params_or_module) -> None:
             c.project_(p.data)
 
 
+def _adopt_layout(state: dict, like: torch.Tensor) -> None:
+    """Brings the moments ``state["m"]``, ``state["v"]`` into the element order of ``like`` (the parameter's memory).  Moments that
+    arrived through ``load_state_dict`` keep the CHECKPOINT's strides -- a model saved with another ``kernel_storage``, or a
+    contiguous round-2 one -- while the update kernel walks w, m, v and g as flat memory: left alone they would be paired with the
+    wrong weights, silently."""
+    for k in ("m", "v"):
+        t = state[k]
+        if t.shape != like.shape or t.dtype != like.dtype or t.device != like.device:
+            raise ValueError(f"KerasAdam: state '{k}' of a parameter of shape {tuple(like.shape)} ({like.dtype}, {like.device}) has "
+                             f"shape {tuple(t.shape)} ({t.dtype}, {t.device})")
+        same = all(d == 1 or x == y for d, x, y in zip(t.shape, t.stride(), like.stride()))
+        if not same:
+            state[k] = torch.empty_like(like).copy_(t)
+
+
 class KerasAdam(torch.optim.Optimizer):
     """Adam for ANY fp32 parameters with Keras 2.11 arithmetic (the reference's optimizer,
     /root/reference/CIFAR-10/nested_quantization_layer/experiment.py:435-443) in ONE launch per <= 256 tensors
@@ -68,6 +83,7 @@ class KerasAdam(torch.optim.Optimizer):
                 if "m" not in st:
                     st["m"] = torch.zeros_like(p.data)
                     st["v"] = torch.zeros_like(p.data)
+                _adopt_layout(st, p.data)
             for k in range(0, len(ps), self._CHUNK):
                 chunk = ps[k:k + self._CHUNK]
                 n = len(chunk)
@@ -81,7 +97,7 @@ class KerasAdam(torch.optim.Optimizer):
                 _hip.check(lib.lq_adam_set_create(w, m, v, cnt, mv, n, ctypes.byref(handle)), "lq_adam_set_create")
                 self._sets.append((group, chunk, handle, (ctypes.c_void_p * n)(), [p.data_ptr() for p in chunk]))
 
-    def __del__(self):
+    def _destroy_sets(self):
         try:
             from . import _hip
             lib = _hip.load()
@@ -89,6 +105,29 @@ class KerasAdam(torch.optim.Optimizer):
                 lib.lq_adam_set_destroy(handle)
         except Exception:
             pass
+        self._sets = None
+
+    def __del__(self):
+        self._destroy_sets()
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["lq_step"] = int(self._step_t.item()) if (self.capturable and self._step_t is not None) else int(self._step)
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """torch replaces the state tensors: the launch tables are rebuilt at the next step (fresh pointers, moments brought into
+        the parameters' element order), and the step counter of the bias correction is restored."""
+        sd = dict(state_dict)
+        step = sd.pop("lq_step", None)
+        super().load_state_dict(sd)
+        self._destroy_sets()
+        if step is not None:
+            self._step = int(step)
+            if self._step_t is not None:
+                self._step_t.fill_(int(step))
+            elif self.capturable:
+                self._pending_step = int(step)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -102,7 +141,8 @@ class KerasAdam(torch.optim.Optimizer):
         lib = _hip.load()
         if self.capturable:
             if self._step_t is None:
-                self._step_t = torch.zeros(1, dtype=torch.int64, device=self._sets[0][1][0].device)
+                self._step_t = torch.full((1,), int(getattr(self, "_pending_step", 0)), dtype=torch.int64,
+                                          device=self._sets[0][1][0].device)
             self._step_t += 1
         else:
             self._step += 1

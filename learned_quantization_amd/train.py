@@ -27,7 +27,8 @@ import torch
 import torch.distributed as dist
 
 from . import layers as L
-from .ddp import DataParallel
+from . import _hip
+from .ddp import CaptureRefused, DataParallel, capture_with_agreement, control_group
 from .losses import SCCEDifference, SCCEInverse, SCCEMaxBin, sparse_categorical_crossentropy
 from .models import INPUT_SHAPES, build_model
 from .optim import KerasAdam, ScaleAdam, non_scale_parameters, scale_parameters
@@ -120,6 +121,8 @@ class Trainer:
         if graph_collectives is None:          # default: capture the collective where the backend can be captured
             graph_collectives = bool(use_dp and dist.get_backend() == "nccl")
         self.graph_collectives = graph_collectives
+        # host-side agreement on capture outcomes (collective creation: every rank builds its Trainer at the same point)
+        self._control = control_group() if (use_dp and graph and graph_collectives) else None
         self.graph_note = None
         self._want_graph = graph
 
@@ -128,14 +131,19 @@ class Trainer:
             per_sample = self.loss_obj.compute_total_loss(y, p)
         else:
             per_sample = sparse_categorical_crossentropy(y, p)
-        total = per_sample.mean()
-        if self._after_exchange:                           # mode B: the regulariser GRADIENTS follow in _update_phase
-            for layer in self.regularized:
-                total = total + layer.regularization_loss().detach()
-            return total
-        for layer in self.regularized:                     # Keras adds regulariser losses to the objective
-            total = total + layer.regularization_loss()
+        return self._with_regularizers(per_sample.mean())
+
+    def _with_regularizers(self, total):
+        """Keras adds the regulariser losses to the objective (custom_layers.py:327).  Exact mode B: their VALUE is added here,
+        their gradients follow in ``_update_phase``, after the scale gradients were recomputed from the pure task-loss P.grad."""
+        for layer in self.regularized:
+            r = layer.regularization_loss()
+            total = total + (r.detach() if self._after_exchange else r)
         return total
+
+    def _objective(self, x, y):
+        """The scalar that is differentiated: task loss of the model's output (+ loss term, + regularisers)."""
+        return self.loss(y, self.model(x))
 
     # ---------------------------------------------------------------- the two phases of a step
     def _backward_phase(self, x, y):
@@ -147,7 +155,7 @@ class Trainer:
             self.scale_opt.zero_grad(set_to_none=True)
         if self.batch is not None:
             self.batch.quantize_all()
-        loss = self.loss(y, self.model(x))
+        loss = self._objective(x, y)
         loss.backward()
         if self.batch is not None and self.loss_obj is not None and not self._after_exchange:
             self._inject_penalty()
@@ -192,22 +200,47 @@ class Trainer:
 
     def _capture_whole_step(self) -> bool:
         """ONE graph: backward phase, RCCL all-reduce (synchronous collectives on the capturing stream), update phase.
-        Returns False -- and leaves the trainer ready for the split form -- when the stack refuses to capture the collective."""
+        The outcome is AGREED ON by all ranks (ddp.capture_with_agreement, over the gloo control group): True when every rank
+        captured; False -- on every rank, with the trainer left ready for the split form -- when the stack refused to record the
+        collective on at least one of them (an error raised while the exchange was being recorded, or when the capture was
+        closed) and the communicator still answers an eager all-reduce afterwards.  Errors of the step itself (argument
+        validation, shapes: anything raised in the backward or update phase, any ``LQError``) are re-raised, on every rank."""
+        phase = ["backward"]
+
         def whole():
             loss = self._backward_phase(self._x, self._y)
+            phase[0] = "exchange"
             self.dp.exchange(capture_safe=True)
+            phase[0] = "update"
             self._update_phase()
+            phase[0] = "end"                 # what is raised from here on comes from closing the capture
             return loss
+
+        def attempt():
+            try:
+                self.graph, self._loss = self._capture(whole)
+            except _hip.LQError:
+                raise
+            except RuntimeError as e:
+                if phase[0] in ("exchange", "end"):
+                    raise CaptureRefused(f"{e!r}"[:300]) from e
+                raise
+
         try:
-            self.graph, self._loss = self._capture(whole)
-            return True
-        except Exception as e:
+            ok = capture_with_agreement(attempt, self._control, health_check=self.dp.health_check)
+        except BaseException:
             self.graph = None
-            self.graph_collectives = False
-            self.graph_note = f"the collective could not be captured ({e!r}"[:200] + "): graph / eager all-reduce / graph"
-            torch.cuda.synchronize(self.device)
-            self.dp.begin_step()
-            return False
+            raise
+        if ok:
+            return True
+        self.graph = None
+        self.graph_collectives = False
+        self.graph_note = "the collective could not be captured on every rank: graph / eager all-reduce / graph"
+        torch.cuda.synchronize(self.device)
+        self.dp.begin_step()                 # arrival counters of the hooks that ran during the abandoned capture
+        if hasattr(self.scale_opt, "_applied"):
+            self.scale_opt._applied = False  # the fused scale update was recorded, not executed
+        return False
 
     def step_graphed(self, x, y):
         """The training step as hipGraph launches.  These steps are launch-bound (hundreds of small kernels); capture

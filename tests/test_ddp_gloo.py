@@ -225,3 +225,68 @@ def test_grad_bucket_single_process():
     assert k.grad.shape == k.shape and k.grad.stride() == k.stride() and not k.grad.is_contiguous()
     (k * torch.arange(48.0).view(4, 3, 2, 2).permute(2, 3, 1, 0)).sum().backward()
     assert torch.equal(b2.flat[64:112], torch.arange(48.0)), "bucket memory in the parameter's memory order"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Collective fallback decisions: the outcome of a capture attempt is agreed on by all ranks.
+
+def _agreement_worker(rank, world, port, scenario, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from learned_quantization_amd.ddp import CaptureRefused, DataParallel, capture_with_agreement, control_group
+    ctl = control_group()
+    model = _FakeLayer(2e-2)
+    dp = DataParallel(model, mode="A", force_collectives=True)
+    state = {"graph": None}
+
+    def attempt():
+        # a "capture": rank 1 fails in the way the scenario says, rank 0 succeeds
+        if rank == 1 and scenario == "refused_on_rank_1":
+            raise CaptureRefused("operation not permitted when stream is capturing")
+        if rank == 1 and scenario == "error_on_rank_1":
+            raise ValueError("a shape bug in the update phase")
+        state["graph"] = "captured"
+
+    result = {"rank": rank}
+    try:
+        ok = capture_with_agreement(attempt, ctl, health_check=dp.health_check)
+        result["ok"] = ok
+        if not ok:
+            state["graph"] = None                    # every rank drops what it captured ...
+        # ... and every rank issues the SAME sequence of collectives afterwards: one eager exchange of the bucket
+        dp.zero_grad()
+        x = torch.ones(4, 12) * (rank + 1)
+        model(x).sum().backward()
+        dp.exchange()
+        result["form"] = "graph" if state["graph"] else "eager"
+        result["grad_sum"] = float(model.W.grad.sum())
+    except BaseException as e:                       # noqa: BLE001
+        result["raised"] = type(e).__name__ + ": " + str(e)[:120]
+    torch.save(result, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["all_captured", "refused_on_rank_1", "error_on_rank_1"])
+def test_capture_outcome_is_agreed_on_by_all_ranks(tmp_path, scenario):
+    """A capture that fails on ONE rank must not leave the ranks on different forms of the step (graph replay on one, eager
+    collectives on the other: a hang).  Refused on rank 1 -> both ranks end on the eager path and their next exchange completes with
+    identical results; an error of the step itself on rank 1 -> rank 1 re-raises it, rank 0 raises too (nobody waits for a dead peer)."""
+    mp.spawn(_agreement_worker, args=(2, _free_port(), scenario, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    if scenario == "all_captured":
+        assert r0["ok"] is True and r1["ok"] is True and r0["form"] == r1["form"] == "graph"
+    elif scenario == "refused_on_rank_1":
+        assert r0["ok"] is False and r1["ok"] is False, (r0, r1)
+        assert r0["form"] == r1["form"] == "eager"
+        assert r0["grad_sum"] == r1["grad_sum"], "the exchange after the agreed fallback completed on both ranks with the same result"
+    else:
+        assert r1["raised"].startswith("ValueError"), r1
+        assert r0["raised"].startswith("RuntimeError") and "another rank failed" in r0["raised"], r0
+
+
+def test_control_group_of_a_gloo_default_group_is_that_group():
+    sys.path.insert(0, ROOT)
+    from learned_quantization_amd.ddp import agree, control_group
+    assert control_group() is None and agree(1, None) == 1          # torch.distributed not initialised: a single process decides alone

@@ -227,7 +227,8 @@ def test_conv_layer_hands_miopen_the_oihw_companion(dev, storage):
     qk = lq.fq_forward(layer.kernel.data, layer.nested_q_k_layer.scale.data)
     qb = lq.fq_forward(layer.b.data, layer.nested_q_b_layer.scale.data)
     y_ref = F.conv2d(x, qk.permute(3, 2, 0, 1).contiguous(), None, 1, 1) + qb.view(1, -1, 1, 1)
-    assert torch.equal(y, y_ref)
+    # two executions of the same convolution: equal up to MIOpen's own run-to-run noise (profiles/r04/rehearsal_diag/)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.cpu().numpy(), rtol=1e-4, atol=1e-6)
     y.square().mean().backward()
     assert layer.kernel.grad is not None and layer.kernel.grad.shape == layer.kernel.shape
     assert layer.kernel.grad.stride() == layer.kernel.stride()
@@ -314,3 +315,22 @@ def test_fused_scale_update_is_refused_where_something_sits_between_gradient_and
     opt = lq.BatchedScaleAdam(b, fused=True)
     with pytest.raises(RuntimeError, match="without a backward"):
         opt.step()
+    # ... and a SECOND scale-gradient pass before step() is refused: the finalize of the first has already applied Adam to the scales
+    # (gradient accumulation or a retried backward would update the scales twice and the weights once)
+    outs = b.quantize_all()
+    torch.autograd.backward(outs, [torch.ones_like(o) * 1e-3 for o in outs])
+    scales = [e.nested.scale.detach().clone() for e in b.entries]
+    opt.zero_grad()
+    for p in m.parameters():
+        p.grad = None
+    outs = b.quantize_all()
+    with pytest.raises(RuntimeError, match="already been applied"):
+        torch.autograd.backward(outs, [torch.ones_like(o) * 1e-3 for o in outs])
+    assert all(torch.equal(s0, e.nested.scale.detach()) for s0, e in zip(scales, b.entries)), "the refused pass changed nothing"
+    opt.step()                                    # acknowledges the first pass; the next step is accepted again
+    opt.zero_grad()
+    for p in m.parameters():
+        p.grad = None
+    outs = b.quantize_all()
+    torch.autograd.backward(outs, [torch.ones_like(o) * 1e-3 for o in outs])
+    opt.step()

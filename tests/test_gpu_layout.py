@@ -139,60 +139,75 @@ def test_batch_and_layers_give_the_same_numbers_for_either_storage(dev, orient):
         for n, p in m.named_parameters():
             assert p.grad is None or p.grad.stride() == p.stride() or p.dim() != 4, f"{n}: the gradient has the parameter's strides"
         res[st] = (probs.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
-    assert torch.equal(res["hwio"][0], res["oihw"][0]), "MIOpen saw the same OIHW tensors"
+    # MIOpen saw the same OIHW tensors; two executions of one convolution need not agree bit for bit (some of its forward kernels
+    # split the reduction and accumulate with atomics: profiles/r04/rehearsal_diag/), an element-order mix-up changes the outputs grossly
+    np.testing.assert_allclose(res["oihw"][0].cpu().numpy(), res["hwio"][0].cpu().numpy(), rtol=1e-4, atol=1e-6)
     for n, g0 in res["hwio"][1].items():
         if "scale" in n:
             continue            # a vote flips when a ratio crosses lambda: ds is not continuous in dW; checked against its own dW below
+        # norm-wise, three orders of magnitude above the noise measured (1e-6 of the tensor's largest gradient): an element-order
+        # mix-up moves elements by the size of the gradients themselves
         g0, g1 = g0.cpu().numpy(), res["oihw"][1][n].cpu().numpy()
-        np.testing.assert_allclose(g1, g0, rtol=1e-4, atol=1e-5 * np.abs(g0).max(), err_msg=n)
+        assert np.abs(g1 - g0).max() <= 1e-3 * np.abs(g0).max(), n
     for st in ("hwio", "oihw"):
         for e in batches[st].entries:
             assert torch.equal(e.nested.scale.grad, lq.fq_scale_grad(e.param.data, e.nested.scale.data, e.param.grad, e.nested.penalty_threshold)), \
                 f"{st}: ds of the batch == the single-tensor op on the gradient that arrived"
 
 
-def _params_agree(a, b, steps, name, lr=1e-4):
-    """Two runs of the same training differ by MIOpen's run-to-run noise (its weight gradients reduce with atomics), and Adam turns
-    an ulp of a near-zero gradient into up to `lr` per step: single elements may be off by `steps` whole steps, the average
-    element by far less than a hundredth of one.  An element-order mix-up moves most elements by whole steps."""
-    d = (a.double() - b.double()).abs()
-    assert float(d.max()) <= steps * lr * 1.25, f"{name}: max difference {float(d.max())}"
-    assert float(d.mean()) <= lr / 100, f"{name}: mean difference {float(d.mean())}"
+def _steps(dev, cls, storage, n, batched, setup, data):
+    tr = cls(*setup, device=dev, seed=7, batched=batched, kernel_storage=storage)
+    if hasattr(tr, "coefficients"):
+        from _linear_task import make_coefficients
+        tr.coefficients = make_coefficients(tr, n)
+    losses = [float(tr.step(*data).detach()) for _ in range(n)]
+    return tr, losses, {k: p.detach().clone() for k, p in tr.model.named_parameters()}
 
 
-def test_training_steps_agree_between_storages(dev):
-    """Three steps of the batched trainer on the CIFAR CNN, `nqcl` (nested quantization + MaxBin loss term): same losses and
-    parameters for either storage (the convolutions and the optimizer see the same numbers; only addresses differ)."""
+@pytest.mark.parametrize("setup", [("cifar", "nqcl", (1e-4, 1e-3), "channelwise", "maxbin"), ("cifar", "nq", 1e-10, "rowwise", None)],
+                         ids=["nqcl-maxbin-channelwise", "nq-rowwise"])
+def test_training_steps_agree_between_storages(dev, setup):
+    """Three steps of the batched trainer on the CIFAR CNN: the same parameters for either storage, BIT FOR BIT, when the upstream
+    gradients are given (tests/_linear_task.py: the product's whole step -- batch forward, STE, scale gradients, MaxBin injection,
+    both optimizers -- with no convolution library in the loop; MaxBin's ds = -(c/G) max/s and the vote sums, exact for lambda < 4e-4,
+    do not depend on the traversal order).  Through MIOpen the same comparison is a sanity check of the losses only: its weight gradients are not
+    run-to-run stable and Adam turns an ulp of a gradient into a whole step (GPUTEST_r03)."""
+    from _linear_task import LinearTaskTrainer
     from learned_quantization_amd.train import Trainer, synthetic_batch
+    out = {st: _steps(dev, LinearTaskTrainer, st, 3, True, setup, (None, None)) for st in ("hwio", "oihw")}
+    assert out["oihw"][1] == out["hwio"][1], "losses"
+    for n, p0 in out["hwio"][2].items():
+        assert torch.equal(out["oihw"][2][n], p0), f"{n}: parameters after three steps"
+    ref = _steps(dev, LinearTaskTrainer, "hwio", 0, True, setup, (None, None))[2]
+    moved = max(float((ref[n] - p0).abs().max()) for n, p0 in out["hwio"][2].items() if "scale" in n)
+    assert moved > 0.0, "the scales moved"
     x, y = synthetic_batch("cifar", 16, dev, torch.Generator(device=dev).manual_seed(0))
-    out = {}
-    for st in ("hwio", "oihw"):
-        tr = Trainer("cifar", "nqcl", (1e-3, 1e-3), "channelwise", "maxbin", device=dev, seed=7, batched=True, kernel_storage=st)
-        tr.model.eval()
-        losses = [float(tr.step(x, y).detach()) for _ in range(3)]
-        out[st] = (losses, {n: p.detach().clone() for n, p in tr.model.named_parameters()})
-    np.testing.assert_allclose(out["oihw"][0], out["hwio"][0], rtol=1e-4)     # later losses inherit the noise of the earlier updates
-    for n, p0 in out["hwio"][1].items():
-        _params_agree(out["oihw"][1][n], p0, 3, n)
+    e2e = {st: _steps(dev, Trainer, st, 3, True, setup, (x, y)) for st in ("hwio", "oihw")}
+    assert all(np.isfinite(l) for st in e2e for l in e2e[st][1])
+    np.testing.assert_allclose(e2e["oihw"][1], e2e["hwio"][1], rtol=1e-3)
 
 
 def test_unbatched_trainer_and_export_on_oihw_storage(dev, tmp_path):
-    """The per-tensor path (ops.my_custom_gradient inside the layer call) and the integer export see the logical HWIO tensor."""
+    """The per-tensor path (ops.my_custom_gradient inside the layer call) and the integer export see the logical HWIO tensor: given
+    upstream gradients, parameters and exported integers are identical for either storage; through MIOpen the losses agree."""
     import learned_quantization_amd as lq
+    from _linear_task import LinearTaskTrainer
     from learned_quantization_amd.train import Trainer, synthetic_batch
-    x, y = synthetic_batch("cifar", 8, dev, torch.Generator(device=dev).manual_seed(0))
+    setup = ("cifar", "nq", 1e-3, "channelwise", None)
     out = {}
     for st in ("hwio", "oihw"):
-        tr = Trainer("cifar", "nq", 1e-3, "channelwise", None, device=dev, seed=7, batched=False, kernel_storage=st)
-        tr.model.eval()
-        losses = [float(tr.step(x, y).detach()) for _ in range(2)]
+        tr, losses, params = _steps(dev, LinearTaskTrainer, st, 2, False, ("cifar", "nq", 1e-10, "channelwise", None), (None, None))
         layer = [l for l in lq.custom_layers_of(tr.model) if hasattr(l, "kernel")][0]
         qi = lq.quantized_integers(layer.kernel.data, layer.nested_q_k_layer.scale.data, torch.int8).cpu().numpy()
         assert qi.shape == tuple(layer.kernel.shape)
-        out[st] = (losses, qi, layer.kernel.detach().cpu().numpy())
-    np.testing.assert_allclose(out["oihw"][0], out["hwio"][0], rtol=1e-4)     # later losses inherit the noise of the earlier updates
-    _params_agree(torch.from_numpy(out["oihw"][2]), torch.from_numpy(out["hwio"][2]), 2, "first conv kernel")
-    assert (out["oihw"][1] != out["hwio"][1]).mean() < 2e-2       # integers differ only where a weight sits within that noise of a bin edge
+        out[st] = (losses, qi, params)
+    assert out["oihw"][0] == out["hwio"][0]
+    for n, p0 in out["hwio"][2].items():
+        assert torch.equal(out["oihw"][2][n], p0), f"{n}: parameters after two steps"
+    assert np.array_equal(out["oihw"][1], out["hwio"][1]), "exported integers"
+    x, y = synthetic_batch("cifar", 8, dev, torch.Generator(device=dev).manual_seed(0))
+    e2e = {st: _steps(dev, Trainer, st, 2, False, setup, (x, y))[1] for st in ("hwio", "oihw")}
+    np.testing.assert_allclose(e2e["oihw"], e2e["hwio"], rtol=1e-3)
 
 
 def test_grad_bucket_keeps_the_parameters_strides(dev):
@@ -204,3 +219,65 @@ def test_grad_bucket_keeps_the_parameters_strides(dev):
     assert k.grad.data_ptr() == b.flat.data_ptr() + 4 * b.offsets[1]
     (k * 2.0).sum().backward()
     assert torch.all(b.flat[b.offsets[1]:b.offsets[1] + k.numel()] == 2.0) and k.grad.data_ptr() == b.views[1].data_ptr()
+
+
+def test_keras_adam_state_saved_from_one_storage_loads_into_the_other(dev):
+    """torch's load_state_dict keeps the checkpoint's strides; KerasAdam updates flat memory.  Moments saved from an
+    HWIO-stored model and loaded into an OIHW-stored one must continue the SAME trajectory, bit for bit."""
+    import learned_quantization_amd as lq
+    g = torch.Generator().manual_seed(4)
+    w0 = torch.randn(3, 3, 8, 16, generator=g) * 0.05
+    grads = [torch.randn(3, 3, 8, 16, generator=g) * 1e-3 for _ in range(4)]
+
+    def param(storage):
+        w = w0.clone().to(dev)
+        return torch.nn.Parameter(_oihw_stored(w) if storage == "oihw" else w)
+    a = param("hwio")
+    opt_a = lq.KerasAdam([a])
+    for gr in grads[:2]:
+        a.grad = gr.to(dev)
+        opt_a.step()
+    sd = opt_a.state_dict()
+    assert sd["lq_step"] == 2
+    b = param("oihw")
+    with torch.no_grad():
+        b.copy_(a)
+    opt_b = lq.KerasAdam([b])
+    opt_b.load_state_dict(sd)
+    for gr in grads[2:]:
+        a.grad = gr.to(dev)
+        opt_a.step()
+        b.grad = _oihw_stored(gr.to(dev))
+        opt_b.step()
+    assert opt_b.state[b]["m"].stride() == b.stride(), "the loaded moments were brought into the parameter's element order"
+    assert torch.equal(a.detach(), b.detach()) and torch.equal(opt_a.state[a]["m"], opt_b.state[b]["m"]) \
+        and torch.equal(opt_a.state[a]["v"], opt_b.state[b]["v"])
+    # ... and a reload into the SAME optimizer after it has run rebuilds its launch tables (fresh state tensors)
+    opt_a.load_state_dict(opt_b.state_dict())
+    a.grad = grads[0].to(dev)
+    b.grad = _oihw_stored(grads[0].to(dev))
+    opt_a.step()
+    opt_b.step()
+    assert torch.equal(a.detach(), b.detach())
+
+
+def test_export_bytes_do_not_depend_on_the_kernel_storage(dev, tmp_path):
+    """The reference's artefact (utils/log_scripts.py:61-97: weights.npy -> zip -> file_sizes.log) for a model with 1x1 convs (the
+    ResNet-18-like net's shortcut convs): identical bytes for either storage -- an OIHW-stored 1x1 kernel is F-contiguous as a numpy
+    array and would otherwise be pickled in Fortran order."""
+    import learned_quantization_amd as lq
+    blobs = {}
+    for st in ("hwio", "oihw"):
+        lq.reset_layer_names()
+        m = lq.build_model("imagenette", mode="nq", value=1e-11, seed=3, orientation="channelwise", device=dev, kernel_storage=st)
+        with torch.no_grad():
+            for s in lq.scale_parameters(m):
+                s.fill_(2e-3)
+        d = tmp_path / st
+        sizes = lq.save_compress_parameters(m, str(d))
+        w = np.load(d / "weights.npy", allow_pickle=True).item()          # written by this test a moment ago
+        assert any(v.ndim == 4 and v.shape[:2] == (1, 1) for v in w.values()), "the model has 1x1 kernels"
+        assert all(v.flags["C_CONTIGUOUS"] for v in w.values())
+        blobs[st] = (open(d / "weights.npy", "rb").read(), open(d / "file_sizes.log").read(), sizes)
+    assert blobs["hwio"][0] == blobs["oihw"][0], "weights.npy bytes"
+    assert blobs["hwio"][1] == blobs["oihw"][1], "file_sizes.log"

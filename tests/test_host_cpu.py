@@ -235,11 +235,56 @@ def test_missing_extension_fails_loudly():
     """No silent fallback: if liblq_hip.so is absent every op raises (checked in a fresh interpreter)."""
     import subprocess
     import sys
-    code = ("import os, sys; os.environ['LQ_HIP_LIB'] = '/nonexistent/liblq_hip.so'; sys.path.insert(0, %r);\n"
+    code = ("import os, sys; sys.path.insert(0, %r);\n"
             "import torch, learned_quantization_amd as lq\n"
+            "lq._hip.use_library('/nonexistent/liblq_hip.so')\n"
             "try:\n    lq.fq_forward(torch.ones(4), torch.ones(1))\nexcept RuntimeError as e:\n    print('RAISED', e)\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert "RAISED" in out.stdout and "HIP extension not built" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_loader_reads_no_environment():
+    """The loader opens the in-tree library whatever the environment says (LQ_HIP_LIB used to swap the
+    library under every op; LQ_SKIP_SELFTEST used to waive the device self-test); development builds are chosen in code."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from learned_quantization_amd import _hip; print(_hip.LIB_PATH)" % ROOT)
+    env = dict(os.environ, LQ_HIP_LIB="/nonexistent/liblq_hip.so", LQ_SKIP_SELFTEST="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert out.stdout.strip().endswith(os.path.join("learned_quantization_amd", "csrc", "liblq_hip.so")), out.stdout + out.stderr
+    src = open(os.path.join(ROOT, "learned_quantization_amd", "_hip.py")).read()
+    assert "os.environ" not in src and "getenv" not in src
+
+
+def test_keras_adam_brings_loaded_moments_into_the_parameters_element_order():
+    """optimizer state saved from a model with another kernel storage keeps the checkpoint's strides through
+    torch's load_state_dict; the flat-memory update must not pair it with the wrong weights."""
+    from learned_quantization_amd.optim import _adopt_layout
+    w = torch.randn(3, 3, 4, 8)
+    p_oihw = w.permute(3, 2, 0, 1).contiguous().permute(2, 3, 1, 0)          # HWIO shape, OIHW memory
+    m, v = torch.randn(3, 3, 4, 8), torch.rand(3, 3, 4, 8)                   # a checkpoint written by an HWIO-contiguous model
+    st = {"m": m.clone(), "v": v.clone()}
+    _adopt_layout(st, p_oihw)
+    for k, ref in (("m", m), ("v", v)):
+        assert st[k].stride() == p_oihw.stride() and torch.equal(st[k], ref)                      # same values index by index
+        flat = torch.as_strided(st[k], (st[k].numel(),), (1,))                                    # ... and what the kernel walks
+        assert torch.equal(flat, ref.permute(3, 2, 0, 1).reshape(-1))
+    st2 = {"m": st["m"], "v": st["v"]}
+    _adopt_layout(st2, p_oihw)
+    assert st2["m"] is st["m"], "already in the parameter's order: left alone"
+    with pytest.raises(ValueError, match="state 'm'"):
+        _adopt_layout({"m": torch.zeros(3, 3, 4, 7), "v": v}, p_oihw)
+
+
+def test_export_arrays_are_c_contiguous_whatever_the_storage():
+    """a 1x1 kernel stored OIHW comes back from .cpu().numpy() F-contiguous; numpy would pickle it in Fortran order."""
+    from learned_quantization_amd.export import _host
+    k = torch.arange(12, dtype=torch.int8).view(1, 1, 3, 4)
+    stored = k.permute(3, 2, 0, 1).contiguous().permute(2, 3, 1, 0)
+    raw = stored.numpy()
+    assert not raw.flags["C_CONTIGUOUS"]
+    h = _host(stored)
+    assert h.flags["C_CONTIGUOUS"] and np.array_equal(h, k.numpy()) and h.tobytes() == k.numpy().tobytes()
 
 
 def test_fast_division_sequence_is_exact_on_cpu(tmp_path):

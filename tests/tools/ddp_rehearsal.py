@@ -11,6 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", sys.argv[1] if len(sys.argv) > 1 else "29541")
@@ -24,6 +25,7 @@ dist.init_process_group("nccl", device_id=dev)          # before any GPU call of
 torch.cuda.set_device(0)
 
 from learned_quantization_amd.train import Trainer, synthetic_batch  # noqa: E402
+from _linear_task import LinearTaskTrainer, make_coefficients  # noqa: E402
 
 STEPS = 4
 ONLY_CAPTURED_COLLECTIVES = len(sys.argv) > 2 and sys.argv[2] == "collectives"
@@ -33,7 +35,8 @@ X, Y = synthetic_batch("mnist", 32, dev, torch.Generator(device=dev).manual_seed
 def run(graph=False, steps=STEPS, setup=("mnist", "nq", 2e-4, "rowwise", None), data=None, **kw):
     tr = Trainer(*setup, device=dev, seed=42, graph=graph, **kw)
     x, y = data if data is not None else (X, Y)
-    tr.model.eval()                                      # no dropout in the dense model anyway; keeps BN-free determinism explicit
+    # (Trainer._backward_phase puts the model into train() mode every step: dropout masks and batch statistics are part of
+    # these runs; they are reproducible because every run seeds the generators the same way and draws in the same order)
     step = tr.step_graphed if graph else tr.step
     losses = [float(step(x, y).detach()) for _ in range(steps)]
     torch.cuda.synchronize()
@@ -79,14 +82,41 @@ if not ONLY_CAPTURED_COLLECTIVES:
     # the penalty must matter in this comparison: without it the scales end elsewhere
     _, _, pn = run(setup=("mnist", "nq", 2e-4, "rowwise", None), batched=True)
     out["nqcl_vs_nq_scale_diff"] = max(float((p0[k] - pn[k]).abs().max()) for k in p0 if "scale" in k)
+    # ---- exact mode B with a regularised net (the ResNet-18-like one carries l2 terms on its residual convs)
     res18 = ("imagenette", "nq", 1e-11, "channelwise", None)
+
+    def linear_run(steps=3, strip_regularizers=False, **kw):
+        tr = LinearTaskTrainer(*res18, device=dev, seed=42, **kw)
+        assert tr.regularized, "the ResNet-18-like net carries l2 regularisers"
+        tr.coefficients = make_coefficients(tr, steps)
+        if strip_regularizers:
+            tr.regularized = []
+        losses = [float(tr.step(None, None).detach()) for _ in range(steps)]
+        torch.cuda.synchronize()
+        return tr, losses, {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+
+    # (1) THE CONTRACT, bit for bit, with the network out of the loop (tests/_linear_task.py): the upstream gradient of every
+    # fake-quant op is a given tensor, so nothing but this repository's code sits between the objective and the parameters.
+    # Mode B recomputes ds from the pure task-loss P.grad after the exchange and adds the regularisers' gradients afterwards
+    # (custom_layers.py:116-118, 327): with one rank that must BE the plain step -- 11.2 M parameters, three steps, == 0.
+    plain = {True: linear_run(batched=True), False: linear_run(batched=False)}      # like is compared with like: batch / per-tensor ops
+    _, _, p_noreg = linear_run(batched=True, strip_regularizers=True)
+    out["linear_task_regularizers_move_the_parameters"] = diff(plain[True][2], p_noreg)
+    for name, kw in (("linear_task_B_batched_regularized_resnet18", dict(ddp_mode="B", batched=True, force_collectives=True)),
+                     ("linear_task_A_batched_regularized_resnet18", dict(ddp_mode="A", batched=True, force_collectives=True)),
+                     ("linear_task_B_per_tensor_regularized_resnet18", dict(ddp_mode="B", batched=False, force_collectives=True))):
+        tr, l1, p1 = linear_run(**kw)
+        assert tr.dp is not None and tr.dp._collectives
+        _, l0, p0 = plain[kw["batched"]]
+        out[name] = {"max_param_diff": diff(p1, p0), "losses": l1, "ref_losses": l0}
+    # (2) the same comparison THROUGH MIOpen, as a loss-level sanity check only.  Parameters are reported, not judged: MIOpen's
+    # weight gradients are not run-to-run stable and its solver choice depends on what the process ran before (GPUTEST_r03:
+    # two plain runs agreed to 7e-10 on average while the third run of the process differed by 1e-7, from the first forward on)
     d18 = synthetic_batch("imagenette", 2, dev, torch.Generator(device=dev).manual_seed(1))
     tr0, l0, p0 = run(setup=res18, data=d18, steps=2, batched=True)
-    assert tr0.regularized, "the ResNet-18-like net carries l2 regularisers"
-    _, _, p0b = run(setup=res18, data=d18, steps=2, batched=True)       # MIOpen's weight-gradient kernels may not be run-to-run stable
     tr, l1, p1 = run(setup=res18, data=d18, steps=2, ddp_mode="B", batched=True, force_collectives=True)
-    out["B_batched_regularized_resnet18"] = {"max_param_diff": diff(p1, p0), "ref_self_diff": diff(p0b, p0), "losses": l1, "ref_losses": l0,
-                                             "mean_param_diff": mean_diff(p1, p0), "ref_self_mean_diff": mean_diff(p0b, p0)}
+    out["miopen_B_batched_regularized_resnet18"] = {"losses": l1, "ref_losses": l0, "max_param_diff_reported_only": diff(p1, p0),
+                                                     "mean_param_diff_reported_only": mean_diff(p1, p0)}
 # graphed steps against their eager data-parallel counterparts
 graphed = {"graph_split_A_batched": dict(ddp_mode="A", batched=True, force_collectives=True, graph_collectives=False),
            "graph_split_B_batched": dict(ddp_mode="B", batched=True, force_collectives=True, graph_collectives=False),

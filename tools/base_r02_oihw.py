@@ -12,6 +12,8 @@ sys.path.insert(0, os.getcwd())
 import torch  # noqa: E402
 
 import learned_quantization_amd as lq  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: E402,F401  (LQ_HIP_LIB -> _hip.use_library)
 
 assert "_base_r02" in lq.__file__, lq.__file__
 config, orient = sys.argv[1].split(":")

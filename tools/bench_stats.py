@@ -4,6 +4,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import learned_quantization_amd as lq
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: E402,F401  (LQ_HIP_LIB -> _hip.use_library)
 
 dev = torch.device("cuda:0")
 
