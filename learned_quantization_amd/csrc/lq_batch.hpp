@@ -3,6 +3,7 @@
 #define LQ_BATCH_HPP_
 #include "lq_aux_kernels.hpp"
 #include "lq_conv_tile.hpp"
+#include "lq_batch_cols.hpp"
 
 namespace lq {
 
@@ -32,6 +33,7 @@ struct Task {
     int64_t R, L, nc;         // row modes (block size 256)
     int64_t C, rps, nbx;      // column mode (rps = rows per block, nbx = blocks along the columns)
     int col_variant, pad1;
+    FragGeom fg;              // scale-gradient tables, float4 column tiles: partial layout of lq_batch_cols.hpp (fg.F == 0: generic layout)
     int64_t np_pad;           // padded partial count; this task's workspace slice is 4 * np_pad words (u32, u32, f64)
     int64_t ws_off;           // offset of the slice in uint32 words
     int64_t gstride, n1, stride1, n2;   // finalize geometry
@@ -115,6 +117,19 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
     } else if (t.mode == 1) {
         if (t.vec) row_small_body<OP, 4>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
         else row_small_body<OP, 1>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
+    } else if constexpr (OP == OP_BWD) {
+        // scale-gradient pass: float4 tiles run the fragment form (lq_batch_cols.hpp); the generic float4 tile is not instantiated here
+        if (t.col_variant == 0) {
+            col_small_body<OP>(p, (int)t.C, t.rps, (int64_t)b, reinterpret_cast<Acc*>(smem));
+        } else {
+            const uint32_t nbx = (uint32_t)t.nbx;
+            const uint32_t by = b / nbx, bx = b - by * nbx;
+            if (t.col_variant >= 4) {
+                if (t.fg.finner >= 2u) col_frag_tile_body<OP, LQ_BATCH_U2, 2>(p, (uint32_t)t.C, (uint32_t)t.rps, bx, by, t.fg, reinterpret_cast<Acc*>(smem));
+                else col_frag_tile_body<OP, LQ_BATCH_U, 4>(p, (uint32_t)t.C, (uint32_t)t.rps, bx, by, t.fg, reinterpret_cast<Acc*>(smem));
+            }
+            else col_tile_body<OP, 1, 0>(p, t.C, t.rps, (int64_t)bx, (int64_t)by, reinterpret_cast<Acc*>(smem));
+        }
     } else {
         col_body<OP, false>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b, t.n1, reinterpret_cast<Acc*>(smem));
     }
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_adam(const AdamTask* __restric
 // The emitting thread fetches the scale's Adam state BEFORE it walks the partials, so that after the reduction only arithmetic
 // and three stores remain.
 struct FinBlock {
-    uint32_t task;        // bit 31: wide form; bit 30: column form
+    uint32_t task;        // bit 31: wide form; bit 30: column form; bit 29: fragment form (lq_batch_cols.hpp)
     uint32_t g0;          // first group of this block within the task
 };
 
@@ -250,8 +265,8 @@ __global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict
     static_assert(O::kStdMerge, "wave-per-group finalize needs the DPP merge (no block barrier)");
     __shared__ AccW col_tot[256];
     const FinBlock fb = blocks[blockIdx.x];
-    const bool wide = (fb.task >> 31) != 0, cols = ((fb.task >> 30) & 1u) != 0;
-    const Task& t = tasks[fb.task & 0x3fffffffu];
+    const bool wide = (fb.task >> 31) != 0, cols = ((fb.task >> 30) & 1u) != 0, frag = ((fb.task >> 29) & 1u) != 0;
+    const Task& t = tasks[fb.task & 0x1fffffffu];
     Params p = t.p;
     p.pa = ws + t.ws_off;
     p.pb = p.pa + t.np_pad;
@@ -267,8 +282,9 @@ __global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict
     f.o1 = nullptr;
     f.o2 = nullptr;
     f.accum = 0;
-    if (cols) {                               // finalize_cols_body (lq_traverse.hpp): 64 / n2 groups per block, whole partial rows
-        const int gpb = 64 / (int)t.n2;
+    if (cols || frag) {                       // finalize_cols_body (lq_traverse.hpp): 64 / n2 groups per block, whole partial rows;
+                                              // finalize_frag_body (lq_batch_cols.hpp): fg.gpb groups per block, one or two fragments each
+        const int gpb = frag ? (int)t.fg.gpb : 64 / (int)t.n2;
         const int64_t gp = (int64_t)fb.g0 + threadIdx.x;                      // the group this thread will hold (threads < gpb)
         const bool update = ah.on && t.am && (int)threadIdx.x < gpb && gp < p.G;
         AdamCoef c;
@@ -281,7 +297,9 @@ __global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict
         }
         int64_t g;
         AccW acc;
-        if (finalize_cols_body<OP>(p, f, (int64_t)fb.g0, col_tot, g, acc)) {
+        const bool holds = frag ? finalize_frag_body<OP>(p, t.fg, t.n1, p.G, fb.g0, col_tot, g, acc)
+                                : finalize_cols_body<OP>(p, f, (int64_t)fb.g0, col_tot, g, acc);
+        if (holds) {
             const float dsg = FinT<OP>::emit(p, f, g, acc);
             if (update) {
                 adam_value(ah, c, dsg, mi, vi, w, t.amin);

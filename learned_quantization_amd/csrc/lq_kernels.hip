@@ -1495,9 +1495,34 @@ static void conv_tile_fin(const ConvTile& ct, int64_t G, int64_t& gstride, int64
     (void)G;
 }
 
-static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, bool allow_tile, lq_task_table& tb) {
+// Row blocks of the batch's scale-gradient column tiles are sized by the BATCH, not per tensor: make_plan aims at about 512 blocks
+// per tensor (right for a launch of its own); 40 or 108 tensors in one launch then make 2000-5300 blocks of 2-8 K elements, more than
+// the chip holds at once -- the second round of blocks ran on a nearly idle chip (profiles/r03/timelines/) -- and 4-8 times the
+// partials the launch needs.  Every float4 column tile of the scale-gradient table gets about `w` elements per block instead, with
+// `w` chosen so that the whole launch is one resident round.
+static double batch_block_elements(double total_elements) {
+    LQ_KNOB(w, "LQ_TUNE_BATCH_W", 0);                  // development: force the elements per block
+    if (w > 0) return (double)w;
+    LQ_KNOB(nb, "LQ_TUNE_BATCH_NB", 1280);             // blocks the chip holds at once: 256 CUs x 5 (k_batch_traverse<OP_BWD>: 5 waves per SIMD)
+    const double per = total_elements / (double)nb;
+    return per < 8192.0 ? 8192.0 : per;
+}
+
+static void batch_rows_per_block(Plan& pl, int64_t outer, double w) {
+    const int64_t tilew = pl.C < 256 ? pl.C : 256;
+    int64_t rb = ceil_div((int64_t)w, tilew);
+    rb = ceil_div(rb, 16) * 16;                        // whole rounds of four waves x four rows
+    if (rb > outer) rb = outer;
+    const int64_t nby = ceil_div(outer, rb);
+    rb = ceil_div(ceil_div(outer, nby), 4) * 4;        // even out the row blocks
+    if (rb > outer) rb = outer;
+    pl.rps = rb;
+    pl.ysplit = ceil_div(outer, rb);
+}
+
+static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, bool allow_tile, lq_task_table& tb, double batch_w = 0.0) {
     memset(&t, 0, sizeof(t));
-    const Plan pl = make_plan(d.outer, d.G, d.inner, kBlock);
+    Plan pl = make_plan(d.outer, d.G, d.inner, kBlock);
     t.p = base_params(d.P, d.s, d.outer, d.G, d.inner);
     t.p.out = d.out;
     t.p.dy = d.dy;
@@ -1520,9 +1545,33 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, bool allow_tile
     t.L = pl.L;
     t.nc = pl.nc;
     t.C = pl.C;
-    t.rps = pl.rps;
     t.nbx = 0;
-    if (!tile && pl.mode == MODE_COL) col_variant(pl, d.P, nullptr, bwd ? nullptr : d.out, t.col_variant, t.nbx, false);
+    if (!tile && pl.mode == MODE_COL) {
+        col_variant(pl, d.P, nullptr, bwd ? nullptr : d.out, t.col_variant, t.nbx, false);
+        // scale-gradient table of the plain (non-companion) pass: float4 tiles run lq_batch_cols.hpp -- batch-sized row blocks, one
+        // partial per (row block, group fragment)
+        if (batch_w > 0.0 && t.col_variant >= 4 && pl.C < (1ll << 30) && d.outer < (1ll << 31)) {
+            batch_rows_per_block(pl, d.outer, batch_w);
+            LQ_KNOB(frag, "LQ_TUNE_BATCH_FRAG", 1);    // development: 0 = a partial per column (the generic layout)
+            const bool grouped = frag && d.inner > 1 && d.inner <= 64;
+            t.fg = make_frag_geom(d.G, d.inner, pl.C, grouped);
+            if (!grouped) t.fg.F = (uint32_t)pl.C;
+            pl.np = pl.ysplit * (int64_t)t.fg.F;
+            pl.n1 = pl.ysplit;
+            if (grouped) {                             // read by finalize_frag_body through t.fg; kept consistent for the workspace bound
+                pl.gstride = 0;
+                pl.stride1 = t.fg.F;
+                pl.n2 = 1;
+            } else {
+                t.fg.gpb = 0;
+            }
+        } else if (batch_w > 0.0 && t.col_variant >= 4) {
+            // a matrix beyond the 32-bit extents of that form (2^30 columns): the scalar column tile, generic layout
+            t.col_variant = 1;
+            t.nbx = ceil_div(pl.C, 64);
+        }
+    }
+    t.rps = pl.rps;
     int64_t blocks;
     if (tile) {
         blocks = (int64_t)t.ct.ntc * t.ct.nto;
@@ -1613,10 +1662,11 @@ static int finish_table(lq_task_table& tb, bool bwd) {
         std::vector<FinBlock> fb;
         for (size_t k = 0; k < n; ++k) {
             const Task& t = tb.h[k];
-            const bool cols = finalize_cols_ok(t.p.G, t.gstride, t.n1, t.stride1, t.n2);      // the rule of the single-tensor finalize
-            const bool wide = !cols && t.n1 * t.n2 > 256;
-            const int64_t per = cols ? 64 / t.n2 : (wide ? 1 : 4);
-            const uint32_t flag = cols ? 0x40000000u : (wide ? 0x80000000u : 0u);
+            const bool frag = t.fg.gpb != 0;                                                  // lq_batch_cols.hpp: fragments of fg.gpb groups per block
+            const bool cols = !frag && finalize_cols_ok(t.p.G, t.gstride, t.n1, t.stride1, t.n2);      // the rule of the single-tensor finalize
+            const bool wide = !frag && !cols && t.n1 * t.n2 > 256;
+            const int64_t per = frag ? (int64_t)t.fg.gpb : (cols ? 64 / t.n2 : (wide ? 1 : 4));
+            const uint32_t flag = frag ? 0x20000000u : (cols ? 0x40000000u : (wide ? 0x80000000u : 0u));
             for (int64_t g = 0; g < t.p.G; g += per) fb.push_back({(uint32_t)k | flag, (uint32_t)g});
         }
         if (fb.size() > 0x7fffffffull) return fail(LQ_EINVAL, "lq_batch_create: too many groups");
@@ -1658,6 +1708,11 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
     if (!b) return fail(LQ_EHIP, "lq_batch_create: out of host memory");
     b->n = n;
     int rc = LQ_OK;
+    double bwd_elements = 0.0;             // elements the scale-gradient pass traverses: sizes its row blocks (batch_block_elements)
+    for (int i = 0; i < n; ++i)
+        if (descs[i].lambda == descs[i].lambda && descs[i].outer > 0 && descs[i].G > 0 && descs[i].inner > 0)
+            bwd_elements += (double)descs[i].outer * (double)descs[i].G * (double)descs[i].inner;
+    const double batch_w = batch_block_elements(bwd_elements);
     for (int i = 0; i < n && !rc; ++i) {
         const lq_tensor_desc& d = descs[i];
         rc = check_desc(d.outer, d.G, d.inner);
@@ -1690,7 +1745,7 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
                 break;
             }
             Task tb;
-            if ((rc = fill_task(tb, d, true, false, b->bwd))) break;
+            if ((rc = fill_task(tb, d, true, false, b->bwd, batch_w))) break;
             if (d.m && d.v) {           // the finalize can apply the scale's Adam step itself (lq_batch_scale_grad_step)
                 tb.am = d.m;
                 tb.av = d.v;

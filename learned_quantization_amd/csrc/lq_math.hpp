@@ -272,6 +272,93 @@ __device__ __forceinline__ void nq_accumulate4c(const float4& q, const float4& o
     }
 }
 
+// ---- float4 whose four elements belong to at most TWO adjacent groups, A then B: elements 0 .. nA-1 are A's (nA = 1..4).  The
+// column traversals of lq_batch_cols.hpp use it where `inner` >= 2: two contexts and two accumulators per lane instead of four
+// (12 VGPRs less than the per-column form), the element's group picked by a lane mask.  Per-group totals are those of the
+// per-column form: max and counts are order-free, the vote sums exact for tmode 0 (lq_common.hpp Acc).
+struct Ctx2 {
+    float sA, rA, sB, rB;
+    float lam_hi;
+    int ok;       // bit 0: both divisors inside the fast-division window; bit 1: both `sure_ok`
+};
+
+__device__ __forceinline__ void fq_core4g(const float4& x, const Ctx2& c, bool m1, bool m2, bool m3, float4& q, float4& o) {
+    const float s0 = c.sA, s1 = m1 ? c.sB : c.sA, s2 = m2 ? c.sB : c.sA, s3 = m3 ? c.sB : c.sA;
+    const float amax = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+    const float amin = fminf(fminf(fabsf(x.x), fabsf(x.y)), fminf(fabsf(x.z), fabsf(x.w)));
+    float4 t;
+    if (__builtin_expect(((c.ok & 1) != 0) & (amin >= 8.271806125530277e-25f) & (amax < 2.4178516392292583e+24f), 1)) {
+        const float r1 = m1 ? c.rB : c.rA, r2 = m2 ? c.rB : c.rA, r3 = m3 ? c.rB : c.rA;
+        t.x = fast_div(x.x, s0, c.rA);
+        t.y = fast_div(x.y, s1, r1);
+        t.z = fast_div(x.z, s2, r2);
+        t.w = fast_div(x.w, s3, r3);
+    } else {
+        t.x = x.x / s0;
+        t.y = x.y / s1;
+        t.z = x.z / s2;
+        t.w = x.w / s3;
+    }
+    q.x = floorf(t.x); q.y = floorf(t.y); q.z = floorf(t.z); q.w = floorf(t.w);
+    o.x = q.x * s0; o.y = q.y * s1; o.z = q.z * s2; o.w = q.w * s3;
+}
+
+template <int TM>
+__device__ __forceinline__ void vote_tally_g(float ratio, float lam, bool m, Acc& A, Acc& B) {
+    const bool below = !(ratio >= lam);                  // NaN counts as "not above"
+    const float t = below ? abs_tanh_t<TM>(lam - ratio) : 0.0f;
+    A.b += (below & !m) ? 1u : 0u;
+    B.b += (below & m) ? 1u : 0u;
+    A.c -= (double)(m ? 0.0f : t);
+    B.c -= (double)(m ? t : 0.0f);
+}
+
+template <int TM>
+__device__ __forceinline__ void vote_cast4g(const float4& dy, float b0, float b1, float b2, float b3, float lam, bool m1, bool m2, bool m3,
+                                            Acc& A, Acc& B) {
+    const float a0 = fabsf(dy.x), a1 = fabsf(dy.y), a2 = fabsf(dy.z), a3 = fabsf(dy.w);
+    const float lo = fminf(fminf(fminf(a0, a1), fminf(a2, a3)), fminf(fminf(b0, b1), fminf(b2, b3)));
+    const float hi = fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)), fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
+    const float nan_probe = (a0 + a1) + (a2 + a3) + ((b0 + b1) + (b2 + b3));
+    float r0, r1, r2, r3;
+    if ((lo >= kWinLo) & (hi <= kWinHi) & (nan_probe == nan_probe)) {
+        r0 = window_div(a0, b0);
+        r1 = window_div(a1, b1);
+        r2 = window_div(a2, b2);
+        r3 = window_div(a3, b3);
+    } else {
+        r0 = a0 / b0;
+        r1 = a1 / b1;
+        r2 = a2 / b2;
+        r3 = a3 / b3;
+    }
+    vote_tally_g<TM>(r0, lam, false, A, B);
+    vote_tally_g<TM>(r1, lam, m1, A, B);
+    vote_tally_g<TM>(r2, lam, m2, A, B);
+    vote_tally_g<TM>(r3, lam, m3, A, B);
+}
+
+__device__ __forceinline__ void nq_accumulate4g(const float4& q, const float4& o, const float4& dy, const Ctx2& c, float lam, int tmode,
+                                                bool m1, bool m2, bool m3, Acc& A, Acc& B) {
+    const float q0 = fabsf(q.x), q1 = fabsf(q.y), q2 = fabsf(q.z), q3 = fabsf(q.w);
+    const float mA = fmaxf(fmaxf(q0, m1 ? 0.0f : q1), fmaxf(m2 ? 0.0f : q2, m3 ? 0.0f : q3));
+    const float mB = fmaxf(m1 ? q1 : 0.0f, fmaxf(m2 ? q2 : 0.0f, m3 ? q3 : 0.0f));
+    A.a = __float_as_uint(fmaxf(__uint_as_float(A.a), mA));
+    B.a = __float_as_uint(fmaxf(__uint_as_float(B.a), mB));
+    const float b0 = (o.x == 0.0f) ? kEpsF32 : fabsf(o.x);   // :63
+    const float b1 = (o.y == 0.0f) ? kEpsF32 : fabsf(o.y);
+    const float b2 = (o.z == 0.0f) ? kEpsF32 : fabsf(o.z);
+    const float b3 = (o.w == 0.0f) ? kEpsF32 : fabsf(o.w);
+    const float lh = c.lam_hi;
+    const bool all_sure = ((c.ok & 2) != 0) & (fabsf(dy.x) >= lh * b0) & (fabsf(dy.y) >= lh * b1) & (fabsf(dy.z) >= lh * b2) &
+                          (fabsf(dy.w) >= lh * b3);
+    if (!all_sure) {
+        if (tmode == 0) vote_cast4g<0>(dy, b0, b1, b2, b3, lam, m1, m2, m3, A, B);
+        else if (tmode == 1) vote_cast4g<1>(dy, b0, b1, b2, b3, lam, m1, m2, m3, A, B);
+        else vote_cast4g<2>(dy, b0, b1, b2, b3, lam, m1, m2, m3, A, B);
+    }
+}
+
 template <int Q>
 __device__ __forceinline__ void store_q_scalar(void* qp, int64_t i, float q) {
     if (Q == LQ_Q_F32) {

@@ -122,6 +122,13 @@ class KerasAdam(torch.optim.Optimizer):
         step = sd.pop("lq_step", None)
         super().load_state_dict(sd)
         self._destroy_sets()
+        # now, not at the next step: torch's load_state_dict copies shallowly -- until they are re-laid out the loaded moments may
+        # still be the tensors of the optimizer the state came from
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "m" in st and "v" in st:
+                    _adopt_layout(st, p.data)
         if step is not None:
             self._step = int(step)
             if self._step_t is not None:

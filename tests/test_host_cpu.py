@@ -309,6 +309,17 @@ def test_invariant_divisor_division_is_exact_on_cpu(tmp_path):
     assert res.returncode == 0 and " 0 mismatches" in res.stdout, res.stdout + res.stderr
 
 
+def test_fragment_index_arithmetic_is_exact_on_cpu(tmp_path):
+    """tests/tools/check_frag.cpp: csrc/lq_frag.hpp (where a (row block, tile, group) partial of the batch's column traversals lives,
+    and which fragments a finalize block reads) == a brute-force walk over the columns, for every group width 1..64 x 16 group counts."""
+    import subprocess
+    exe = str(tmp_path / "check_frag")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "learned_quantization_amd", "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "tools", "check_frag.cpp")])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and " 0 mismatches" in res.stdout, res.stdout + res.stderr
+
+
 def test_batch_abi_validation_without_gpu():
     """lq_batch_* argument checks that return before any HIP call."""
     import ctypes
