@@ -33,13 +33,21 @@ class _Entry:
 
 class FakeQuantBatch:
     def __init__(self, model_or_layers, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-7, mode: str = "keras",
-                 oihw: bool = True, hwio_out: bool = True):
-        """``oihw``: conv kernels of nested-quantization layers get an OIHW companion output (what MIOpen consumes).
+                 oihw: bool = True, hwio_out: bool = True, autograd: bool = True):
+        """``autograd=True``: ``quantize_all()`` is ONE autograd node (2 x tensors inputs, one output per tensor) and everything happens
+        inside ``loss.backward()``.  Convenient -- and, for 40 tensors, 0.4-0.6 ms of autograd-engine work per step (an 80-input node,
+        40 output wrappers, an AccumulateGrad per parameter that adds into the data-parallel bucket with a launch of its own).
+        ``autograd=False`` (the trainer's form): the fake-quantised tensors are persistent LEAVES -- autograd only delivers their
+        gradients (``leaf.grad``, stolen from the producer: no launch) -- and ``finish_backward()`` after ``loss.backward()`` runs
+        the scale-gradient launches and hands ``dP = dy`` (custom_layers.py:118) to the parameters: by reference where a parameter
+        has no gradient yet, with one fused add over all others (bucket views, regularised kernels).
+        ``oihw``: conv kernels of nested-quantization layers get an OIHW companion output (what MIOpen consumes).
         ``hwio_out=False``: where the LDS-tile kernel writes that companion, the HWIO output is not materialised at all -- in a
         training step the convolution is the kernel's only consumer (custom_layers.py:340-348), so the forward moves 8 bytes
         per element instead of 12; ``quantize_all()`` then returns the HWIO tensor as a permuted VIEW of the companion."""
         layers = custom_layers_of(model_or_layers) if isinstance(model_or_layers, torch.nn.Module) else list(model_or_layers)
         self.layers = layers
+        self.autograd = bool(autograd)
         self._external_grads = False
         self._fused_opt = None               # BatchedScaleAdam(fused=True): the scale-gradient finalize applies the Adam step itself
         self.defer_scale_grads = False       # exact data-parallel mode: backward skips ds, scale_grads_from_param_grads() follows
@@ -118,6 +126,11 @@ class FakeQuantBatch:
         self._layer_slots = list(slots.values())
         self._oihw_idx = [i for i, e in enumerate(self.entries) if e.out_oihw is not None]     # extra autograd outputs, in this order
         self._oihw_pos = {i: len(self.entries) + k for k, i in enumerate(self._oihw_idx)}
+        if not self.autograd:
+            # persistent leaves over the static output buffers (the forward launch rewrites the memory under them; autograd never
+            # looks at their values, only routes gradients to them)
+            self._leaf = [None if e.out is None else e.out.detach().requires_grad_(True) for e in self.entries]
+            self._leaf_o = [None if e.out_oihw is None else e.out_oihw.detach().requires_grad_(True) for e in self.entries]
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -138,6 +151,8 @@ class FakeQuantBatch:
     def quantize_all(self):
         """One launch: fake-quantise every kernel/bias; layers pick the results up in their next call."""
         self._check_pointers()
+        if not self.autograd:
+            return self._quantize_all_leaves()
         outs = _BatchFn.apply(self, *self._flat)
         n = len(self.entries)
         for layer, ik, ib in self._layer_slots:
@@ -145,6 +160,39 @@ class FakeQuantBatch:
             layer.__dict__["_q_pre"] = (None if ik is None else outs[ik], None if ib is None else outs[ib],
                                         outs[self._oihw_pos[ik]] if ik in self._oihw_pos else None)
         return outs[:n]
+
+    def _quantize_all_leaves(self):
+        _hip.check(_hip.load().lq_batch_forward(self._handle, _hip.stream_ptr(self.device)), "lq_batch_forward")
+        outs = []
+        for lf, lo in zip(self._leaf, self._leaf_o):
+            if lf is not None:
+                lf.grad = None
+            if lo is not None:
+                lo.grad = None
+            outs.append(lf if lf is not None else lo.permute(2, 3, 1, 0))      # the HWIO-shaped view of a companion-only kernel
+        for layer, ik, ib in self._layer_slots:
+            layer.__dict__["_q_pre"] = (None if ik is None else outs[ik], None if ib is None else outs[ib],
+                                        self._leaf_o[ik] if ik is not None else None)
+        return outs
+
+    def finish_backward(self):
+        """``autograd=False``: call after ``loss.backward()``.  Reads the gradients autograd left on the fake-quantised leaves, runs
+        the scale-gradient launches (unless ``defer_scale_grads``: exact data-parallel mode computes them after the exchange) and
+        gives every parameter its ``dP = dy`` (custom_layers.py:118)."""
+        if self.autograd:
+            raise RuntimeError("finish_backward() belongs to FakeQuantBatch(autograd=False)")
+        dys = [None if lf is None else lf.grad for lf in self._leaf] + [self._leaf_o[i].grad for i in self._oihw_idx]
+        dps = self._backward_core(dys)
+        alias_p, add_to, add_from = [], [], []
+        for e, dp in zip(self.entries, dps):
+            p = e.param
+            if p.grad is None:
+                p.grad = dp                                # by reference: no launch (what AccumulateGrad does with a fresh gradient)
+            else:
+                add_to.append(p.grad)                      # a data-parallel bucket view, or the gradient a regulariser left there
+                add_from.append(dp)
+        if add_to:
+            torch._foreach_add_(add_to, add_from)          # one fused launch for all of them
 
     def _scale_grad_call(self, oihw: bool):
         """lq_batch_scale_grad(_oihw), or -- a fused optimizer attached -- lq_batch_scale_grad_step: same launches, the finalize
@@ -168,6 +216,60 @@ class FakeQuantBatch:
                                                 h["lr"], h["betas"][0], h["betas"][1], h["eps"], int(step or 0), _hip.ptr(step_dev),
                                                 md, sp), "lq_batch_scale_grad_step")
         opt._applied = True
+
+    # ------------------------------------------------------------------ backward of every tensor (both modes)
+    def _backward_core(self, dys):
+        """``dys``: upstream gradient of every HWIO-shaped output, then of every OIHW companion (``None`` where nothing consumed
+        it).  Launches the scale-gradient pass (unless deferred), sets ``scale.grad`` and returns ``dP`` per tensor."""
+        batch = self
+        n = len(batch.entries)
+        # a conv kernel with an OIHW companion: its consumer (the convolution) used the companion, so the gradient arrives there,
+        # in OIHW order; a consumer that used the HWIO output instead is served by the plain path below
+        dys = list(dys)
+        oihw_used = False
+        for i in batch._oihw_idx:
+            d_o = dys[batch._oihw_pos[i]]
+            if d_o is not None:
+                if dys[i] is not None:
+                    raise RuntimeError("FakeQuantBatch: both the HWIO and the OIHW output of one conv kernel received a gradient")
+                oihw_used = True
+        if batch.defer_scale_grads:          # dP == dy (custom_layers.py:118); ds follows after the all-reduce
+            dps = []
+            for i, e in enumerate(batch.entries):
+                d = dys[i]
+                if d is None and i in batch._oihw_pos and dys[batch._oihw_pos[i]] is not None:
+                    d = dys[batch._oihw_pos[i]].permute(2, 3, 1, 0)
+                dps.append(d if d is not None else torch.zeros_like(e.param.data))
+            return dps
+        keep = []
+        gathered = set()
+        for i, e in enumerate(batch.entries):
+            d = dys[i]
+            if d is None and i in batch._oihw_pos and dys[batch._oihw_pos[i]] is not None:
+                d = dys[batch._oihw_pos[i]]
+                gathered.add(i)
+            elif d is None:
+                d = torch.zeros_like(e.param.data)
+            elif oihw_used and i in batch._oihw_pos:
+                raise RuntimeError("FakeQuantBatch: conv kernels must all be consumed through the same layout in one step")
+            d = _hip.require_device_f32(d, "dy", like=None if i in gathered else e.param.data)
+            keep.append(d)
+            batch._ptrs[i] = d.data_ptr()
+        for e in batch.entries:
+            if e.nested.penalty_threshold is not None and e.nested.scale.grad is not None and not batch._external_grads:
+                # the kernel OVERWRITES its gradient buffer: a second backward without zero_grad(set_to_none=True)
+                # would silently drop the first gradient -- refuse instead (before anything is launched)
+                raise RuntimeError("FakeQuantBatch: scale gradients must be None before backward "
+                                   "(gradient accumulation over several backward passes is not supported in batched mode)")
+        batch._scale_grad_call(oihw_used)
+        dps = []
+        for i, (e, d) in enumerate(zip(batch.entries, keep)):
+            dps.append(e.dp if i in gathered else d)               # dP is dy itself (custom_layers.py:118), in HWIO order
+            if e.nested.penalty_threshold is not None:
+                e.nested.scale.grad = e.ds                         # written in place by the kernel: no accumulate launch
+            # STE-only: zeros_like(scale) (CL custom_layers.py:62) -- no scale gradient from the op
+        assert len(dps) == n
+        return dps
 
     # ------------------------------------------------------------------ exact data-parallel mode (ddp.py, mode B)
     def scale_grads_from_param_grads(self):
@@ -246,55 +348,10 @@ class _BatchFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dys):
         batch: FakeQuantBatch = ctx.batch
-        lib = _hip.load()
-        n = len(batch.entries)
-        # a conv kernel with an OIHW companion: its consumer (the convolution) used the companion, so the gradient arrives there,
-        # in OIHW order; a consumer that used the HWIO output instead is served by the plain path below
-        dys = list(dys)
-        oihw_used = False
-        for i in batch._oihw_idx:
-            d_o = dys[batch._oihw_pos[i]]
-            if d_o is not None:
-                if dys[i] is not None:
-                    raise RuntimeError("FakeQuantBatch: both the HWIO and the OIHW output of one conv kernel received a gradient")
-                oihw_used = True
-        if batch.defer_scale_grads:          # dP == dy (custom_layers.py:118); ds follows after the all-reduce
-            grads = [None]
-            for i, e in enumerate(batch.entries):
-                d = dys[i]
-                if d is None and i in batch._oihw_pos and dys[batch._oihw_pos[i]] is not None:
-                    d = dys[batch._oihw_pos[i]].permute(2, 3, 1, 0)
-                grads.extend((d if d is not None else torch.zeros_like(e.param.data), None))
-            return tuple(grads)
-        keep = []
-        gathered = set()
-        for i, e in enumerate(batch.entries):
-            d = dys[i]
-            if d is None and i in batch._oihw_pos and dys[batch._oihw_pos[i]] is not None:
-                d = dys[batch._oihw_pos[i]]
-                gathered.add(i)
-            elif d is None:
-                d = torch.zeros_like(e.param.data)
-            elif oihw_used and i in batch._oihw_pos:
-                raise RuntimeError("FakeQuantBatch: conv kernels must all be consumed through the same layout in one step")
-            d = _hip.require_device_f32(d, "dy", like=None if i in gathered else e.param.data)
-            keep.append(d)
-            batch._ptrs[i] = d.data_ptr()
-        batch._scale_grad_call(oihw_used)
+        dps = batch._backward_core(dys)
         grads = [None]
-        for i, (e, d) in enumerate(zip(batch.entries, keep)):
-            grads.append(e.dp if i in gathered else d)             # dP is dy itself (custom_layers.py:118), in HWIO order
-            if e.nested.penalty_threshold is not None:
-                g = e.nested.scale.grad
-                if g is not None and not batch._external_grads:
-                    # the kernel OVERWRITES its gradient buffer: a second backward without zero_grad(set_to_none=True)
-                    # would silently drop the first gradient -- refuse instead
-                    raise RuntimeError("FakeQuantBatch: scale gradients must be None before backward "
-                                       "(gradient accumulation over several backward passes is not supported in batched mode)")
-                e.nested.scale.grad = e.ds                         # written in place by the kernel: no accumulate launch
-                grads.append(None)
-            else:
-                grads.append(None)                                 # STE-only: zeros_like(scale) (CL custom_layers.py:62)
+        for dp in dps:
+            grads.extend((dp, None))       # (dP, d scale): the scale gradient is written in place by the kernel, never through autograd
         return tuple(grads)
 
 

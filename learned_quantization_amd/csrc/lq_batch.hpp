@@ -125,8 +125,8 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
             const uint32_t nbx = (uint32_t)t.nbx;
             const uint32_t by = b / nbx, bx = b - by * nbx;
             if (t.col_variant >= 4) {
-                if (t.fg.finner >= 2u) col_frag_tile_body<OP, LQ_BATCH_U2, 2>(p, (uint32_t)t.C, (uint32_t)t.rps, bx, by, t.fg, reinterpret_cast<Acc*>(smem));
-                else col_frag_tile_body<OP, LQ_BATCH_U, 4>(p, (uint32_t)t.C, (uint32_t)t.rps, bx, by, t.fg, reinterpret_cast<Acc*>(smem));
+                if (t.fg.finner >= 2u) col_frag_tile_body<OP, LQ_BATCH_U2, 2, LQ_BATCH_PIPE>(p, (uint32_t)t.C, (uint32_t)t.rps, bx, by, t.fg, reinterpret_cast<Acc*>(smem));
+                else col_frag_tile_body<OP, LQ_BATCH_U, 4, LQ_BATCH_PIPE>(p, (uint32_t)t.C, (uint32_t)t.rps, bx, by, t.fg, reinterpret_cast<Acc*>(smem));
             }
             else col_tile_body<OP, 1, 0>(p, t.C, t.rps, (int64_t)bx, (int64_t)by, reinterpret_cast<Acc*>(smem));
         }

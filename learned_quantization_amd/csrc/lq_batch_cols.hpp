@@ -29,17 +29,26 @@ namespace lq {
 //  bit for bit there; above, the f64 sums differ below 2^-50 relative as between any two traversals.
 // ------------------------------------------------------------------------------------------
 #ifndef LQ_BATCH_U
-#define LQ_BATCH_U 4          // rows per wave in flight (float4 of each stream per lane and round), per-column form
+#define LQ_BATCH_U 2          // rows per wave and stage (float4 of each stream per lane), per-column form
 #endif
 #ifndef LQ_BATCH_U2
-#define LQ_BATCH_U2 4         // the same for the two-group form
+#define LQ_BATCH_U2 2         // the same for the two-group form
+#endif
+#ifndef LQ_BATCH_PIPE
+#define LQ_BATCH_PIPE 1       // 1: the loads of the next stage are issued before the current stage is consumed (two register sets)
 #endif
 
 // GF = 4: a context and an accumulator per COLUMN of the lane's float4 (any `inner`; the only form for inner == 1, where the four
 //         columns are four groups, and for the per-column layout);
 // GF = 2: two contexts and two accumulators per lane (lq_math.hpp Ctx2: inner >= 2 -- four adjacent columns touch at most two
 //         groups), grouped layout only.
-template <int OP, int U, int GF>
+// PIPE:   every block of a batch launch starts at t = 0 and is resident to the end (one round of blocks), so the waves of the whole
+//         chip march in step: all issue a stage's loads, all wait for them -- 34 MB in flight, 5 us at the memory system's rate --
+//         all consume them while the memory system idles, three times over (block timeline of the unpipelined form,
+//         profiles/r04/timelines/: every block alive for 13 of the launch's 17.4 us; math-free it ran 1.2 us faster).  With two
+//         register sets the next stage is in flight while the current one is consumed.  The prefetch is unconditional (row index
+//         clamped): a conditional load leaves a pending-counter state on one path that the compiler waits out on every path.
+template <int OP, int U, int GF, int PIPE>
 __device__ __forceinline__ void col_frag_tile_body(const Params& p, uint32_t C, uint32_t RB, uint32_t bx, uint32_t by, const FragGeom fg,
                                                    Acc* lds) {
     using O = OpT<OP>;
@@ -48,31 +57,92 @@ __device__ __forceinline__ void col_frag_tile_body(const Params& p, uint32_t C, 
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: row arithmetic stays scalar
     const uint32_t col0 = (bx * 64u + lane) * 4u;
     const bool active = col0 < C;                          // C % 4 == 0: a float4 never straddles a row end
-    const uint32_t voff = (active ? col0 : 0u) * 4u;       // idle lanes of the last tile re-read the row's first float4: loads stay unconditional
+    uint32_t voff = (active ? col0 : 0u) * 4u;             // idle lanes of the last tile re-read the row's first float4: loads stay unconditional
     const uint32_t outer = (uint32_t)p.outer;
     const uint32_t r0 = by * RB;
     const uint32_t r1 = (r0 + RB < outer) ? r0 + RB : outer;
     const size_t row_bytes = (size_t)C * 4u;
     const char* const Pb = reinterpret_cast<const char*>(p.P);
     const char* const Db = reinterpret_cast<const char*>(p.dy);
-    float4 x[U], d[U];
-    auto load_round = [&](uint32_t r) {
+    float4 x0[U], d0[U], x1[PIPE ? U : 1], d1[PIPE ? U : 1];
+    // Row addresses are wave-uniform POINTERS carried from stage to stage (SGPR pairs: global_load ... v_off, s[base:base+1]); a 64-bit
+    // row * pitch product per load would be done per lane in VGPRs (v_mad_u64_u32) -- and the address registers then alias the
+    // destinations of loads still in flight, which makes the compiler wait for those before it can issue the prefetch
+    const size_t step4 = 4u * row_bytes;                   // four waves interleave the rows of a block
+    const char* const lastP = Pb + (size_t)(r1 - 1u) * row_bytes;
+    const char* const lastD = Db + (size_t)(r1 - 1u) * row_bytes;
+    auto load_stage = [&](float4* x, float4* d, uint32_t r, const char* rp, const char* rd) {
+        // the lane offset is re-materialised as a 32-bit value in the block that issues the loads: instruction selection works per
+        // basic block and recognises `uniform base + zext(32-bit VGPR)` (the saddr form) only when it sees the zero-extension there;
+        // hoisted out of the loop as a 64-bit pair the sum is formed per lane (v_lshl_add_u64) in registers that alias pending loads
+        asm volatile("" : "+v"(voff));                     // (in place: a copy would be written into a register that a load in flight still owns)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t rq = r + 4u * (uint32_t)u;
-            const uint32_t rr = rq < r1 ? rq : r1 - 1u;    // clamp (scalar): a round's loads are issued together, unconditionally
-            const size_t ro = (size_t)rr * row_bytes;
-            x[u] = *reinterpret_cast<const float4*>(Pb + ro + voff);
-            d[u] = *reinterpret_cast<const float4*>(Db + ro + voff);
+            const bool in = r + 4u * (uint32_t)u < r1;     // scalar; beyond the block: the block's last row again (loads stay unconditional)
+            const char* const qp = in ? rp + (size_t)u * step4 : lastP;
+            const char* const qd = in ? rd + (size_t)u * step4 : lastD;
+            x[u] = *reinterpret_cast<const float4*>(qp + voff);
+            d[u] = *reinterpret_cast<const float4*>(qd + voff);
         }
     };
-    uint32_t r = r0 + w;
-    const bool any = r < r1;                               // wave-uniform (a row block shorter than four rows leaves waves without work)
-    if (any) load_round(r);
-    __builtin_amdgcn_sched_barrier(0);                     // the first round is in flight while the scales arrive and the contexts are formed
+    // the lane's scales first -- a few words, cache-resident -- then the first stage: vector loads return in order (one vmcnt), so
+    // with the scales ahead of the data the contexts (reciprocals, thresholds) are formed while the first stage is in flight
     const uint32_t inner = (uint32_t)p.inner;
     const uint32_t cg = active ? col0 : 0u;
     const uint32_t g0 = cg / inner, k0 = cg - g0 * inner;
+    float sv[GF == 4 ? 4 : 2];
+    if constexpr (GF == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t g = g0, kk = k0 + (uint32_t)k;        // group of column col0 + k without another division (inner may be < 4)
+            while (kk >= inner) {
+                kk -= inner;
+                ++g;
+            }
+            sv[k] = p.s[g];
+        }
+    } else {
+        sv[0] = p.s[g0];
+        sv[1] = p.s[(g0 + 1u < (uint32_t)p.G) ? g0 + 1u : g0];
+    }
+    uint32_t r = r0 + w;
+    const bool any = r < r1;                               // wave-uniform (a row block shorter than four rows leaves waves without work)
+    const char* rp = Pb + (size_t)r * row_bytes;           // row r of either stream
+    const char* rd = Db + (size_t)r * row_bytes;
+    const size_t stage = (size_t)U * step4;
+    load_stage(x0, d0, r, rp, rd);                         // also in a wave without rows (clamped to the block's last row): one path, so
+    __builtin_amdgcn_sched_barrier(0);                     // that the wait for the scales below does not have to cover the data as well
+    // stage loop: `consume(x, d, r)` folds the rows r, r + 4, ... of one stage
+    auto run = [&](auto&& consume) {
+        if (!any) return;
+        if constexpr (PIPE != 0) {
+            for (;;) {
+                load_stage(x1, d1, r + 4u * U, rp + stage, rd + stage);
+                __builtin_amdgcn_sched_barrier(0);         // nothing that reads the current stage moves above the prefetch
+                consume(x0, d0, r);
+                r += 4u * U;
+                rp += stage;
+                rd += stage;
+                if (r >= r1) break;
+                load_stage(x0, d0, r + 4u * U, rp + stage, rd + stage);
+                __builtin_amdgcn_sched_barrier(0);
+                consume(x1, d1, r);
+                r += 4u * U;
+                rp += stage;
+                rd += stage;
+                if (r >= r1) break;
+            }
+        } else {
+            for (;;) {
+                consume(x0, d0, r);
+                r += 4u * U;
+                rp += stage;
+                rd += stage;
+                if (r >= r1) break;
+                load_stage(x0, d0, r, rp, rd);
+            }
+        }
+    };
     const uint32_t X0 = bx * 256u;
     const uint32_t X1 = (X0 + 256u < C) ? X0 + 256u : C;
     const uint32_t gA = X0 / fg.finner;
@@ -85,27 +155,17 @@ __device__ __forceinline__ void col_frag_tile_body(const Params& p, uint32_t C, 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             acc[k] = O::template init<Acc>();
-            uint32_t g = g0, kk = k0 + (uint32_t)k;        // group of column col0 + k without another division (inner may be < 4)
-            while (kk >= inner) {
-                kk -= inner;
-                ++g;
-            }
-            ctx[k] = O::ctx(p, (int64_t)g);
+            ctx[k] = O::ctx_of(p, sv[k]);
         }
-        if (any) {
-            for (;;) {
+        run([&](const float4* x, const float4* d, uint32_t rs) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (r + 4u * (uint32_t)u < r1) {       // scalar condition
-                        if (LQ_ABLATE(1)) acc[0].a |= __float_as_uint(x[u].x) ^ __float_as_uint(d[u].w) ^ __float_as_uint(x[u].z + d[u].y);      // development: math-free
-                        else O::elem4c(p, ctx, 0, x[u], d[u], acc);
-                    }
+            for (int u = 0; u < U; ++u) {
+                if (rs + 4u * (uint32_t)u < r1) {          // scalar condition
+                    if (LQ_ABLATE(1)) acc[0].a |= __float_as_uint(x[u].x) ^ __float_as_uint(d[u].w) ^ __float_as_uint(x[u].z + d[u].y);      // development: math-free
+                    else O::elem4c(p, ctx, 0, x[u], d[u], acc);
                 }
-                r += 4u * U;
-                if (r >= r1) break;
-                load_round(r);
             }
-        }
+        });
         if (LQ_ABLATE(8)) {                                // development: no epilogue (one dummy word keeps the accumulators alive)
             if ((acc[0].a ^ acc[1].a ^ acc[2].a ^ acc[3].a) == 0x12345u && acc[0].c + acc[1].c + acc[2].c + acc[3].c == 1.5) p.pa[pbase] = 1u;
             return;
@@ -130,8 +190,7 @@ __device__ __forceinline__ void col_frag_tile_body(const Params& p, uint32_t C, 
         // two groups per lane: A = group of column col0 (elements 0 .. nA-1), B = the next one
         const uint32_t nA = inner - k0;                    // >= 1; >= 4: the whole float4 is A's
         const bool m1 = nA < 2u, m2 = nA < 3u, m3 = nA < 4u;
-        const uint32_t gB = (g0 + 1u < (uint32_t)p.G) ? g0 + 1u : g0;
-        const Ctx cA = O::ctx(p, (int64_t)g0), cB = O::ctx(p, (int64_t)gB);
+        const Ctx cA = O::ctx_of(p, sv[0]), cB = O::ctx_of(p, sv[1]);
         Ctx2 c2;
         c2.sA = cA.s;
         c2.rA = cA.r;
@@ -140,25 +199,20 @@ __device__ __forceinline__ void col_frag_tile_body(const Params& p, uint32_t C, 
         c2.lam_hi = cA.lam_hi;
         c2.ok = (cA.fast & cB.fast & 1) | ((cA.sure_ok & cB.sure_ok & 1) << 1);
         Acc A = O::template init<Acc>(), B = O::template init<Acc>();
-        if (any) {
-            for (;;) {
+        run([&](const float4* x, const float4* d, uint32_t rs) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (r + 4u * (uint32_t)u < r1) {       // scalar condition
-                        if (LQ_ABLATE(1)) {                // development: math-free
-                            A.a |= __float_as_uint(x[u].x) ^ __float_as_uint(d[u].w) ^ __float_as_uint(x[u].z + d[u].y);
-                        } else {
-                            float4 q, o;
-                            fq_core4g(x[u], c2, m1, m2, m3, q, o);
-                            nq_accumulate4g(q, o, d[u], c2, p.lam, p.tmode, m1, m2, m3, A, B);
-                        }
+            for (int u = 0; u < U; ++u) {
+                if (rs + 4u * (uint32_t)u < r1) {          // scalar condition
+                    if (LQ_ABLATE(1)) {                    // development: math-free
+                        A.a |= __float_as_uint(x[u].x) ^ __float_as_uint(d[u].w) ^ __float_as_uint(x[u].z + d[u].y);
+                    } else {
+                        float4 q, o;
+                        fq_core4g(x[u], c2, m1, m2, m3, q, o);
+                        nq_accumulate4g(q, o, d[u], c2, p.lam, p.tmode, m1, m2, m3, A, B);
                     }
                 }
-                r += 4u * U;
-                if (r >= r1) break;
-                load_round(r);
             }
-        }
+        });
         if (LQ_ABLATE(8)) {                                // development: no epilogue
             if ((A.a ^ B.a) == 0x12345u && A.c + B.c == 1.5) p.pa[pbase] = 1u;
             return;

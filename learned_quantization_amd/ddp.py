@@ -233,6 +233,7 @@ class DataParallel:
         self.overlap = overlap and self._collectives
         self._hooks_on = True
         self._synced = False
+        self._hold = set()                # sub-buckets that only exchange() may launch (attach_batch)
         limit = max(int(bucket_mb * (1 << 20) / 4), 1)
         offsets = self.bucket.offsets
         hi = self.bucket.flat.numel()
@@ -263,6 +264,12 @@ class DataParallel:
         self._batch = batch
         if self.mode == "B":
             batch.defer_scale_grads = True
+        if not getattr(batch, "autograd", True):
+            # FakeQuantBatch(autograd=False) hands dP to its parameters in finish_backward(), after loss.backward() has returned: a
+            # sub-bucket that holds one of them must not be exchanged from a hook -- a regularised kernel's hook fires for the
+            # regulariser's gradient alone -- but by exchange(), which the step calls after finish_backward()
+            managed = {id(e.param) for e in batch.entries} | {id(e.nested.scale) for e in batch.entries}
+            self._hold = {self._param_bucket[i] for i, p in enumerate(self.bucket.params) if id(p) in managed}
 
     def no_sync(self):
         """Context manager: backward passes inside accumulate into the bucket without exchanging anything."""
@@ -287,7 +294,7 @@ class DataParallel:
                                    "backward without dp.zero_grad().  For gradient accumulation run the earlier backward "
                                    "passes under `with dp.no_sync():`")
             self._remaining[b] -= 1
-            if self._remaining[b] == 0 and self.overlap:
+            if self._remaining[b] == 0 and self.overlap and b not in self._hold:
                 self._launch(b)
         return hook
 

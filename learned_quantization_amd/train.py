@@ -106,7 +106,9 @@ class Trainer:
             from .batch import BatchedScaleAdam, FakeQuantBatch
             if self.dp is not None:
                 self.dp.zero_grad()          # makes scale.grad the bucket views the batch will write into
-            self.batch = FakeQuantBatch(self.model, lr=lr, hwio_out=False)     # the convolutions consume the OIHW companions only
+            # the convolutions consume the OIHW companions only; autograd=False: the fake-quantised tensors are leaves and
+            # _backward_phase calls finish_backward() itself (0.4-0.6 ms less autograd-engine work per eager step for 40 tensors)
+            self.batch = FakeQuantBatch(self.model, lr=lr, hwio_out=False, autograd=False)
             # nothing touches ds between its computation and the scales' update when there is no loss term and ds is not
             # exchanged (one process, or exact mode B): the finalize then applies the Adam step itself (one launch fewer)
             fused = self.loss_obj is None and (self.dp is None or ddp_mode == "B")
@@ -157,6 +159,8 @@ class Trainer:
             self.batch.quantize_all()
         loss = self._objective(x, y)
         loss.backward()
+        if self.batch is not None:
+            self.batch.finish_backward()         # scale-gradient launches; dP = dy to every quantised parameter
         if self.batch is not None and self.loss_obj is not None and not self._after_exchange:
             self._inject_penalty()
         return loss

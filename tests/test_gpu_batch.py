@@ -334,3 +334,47 @@ def test_fused_scale_update_is_refused_where_something_sits_between_gradient_and
     outs = b.quantize_all()
     torch.autograd.backward(outs, [torch.ones_like(o) * 1e-3 for o in outs])
     opt.step()
+
+
+@pytest.mark.parametrize("config,orient,storage", [("cifar", "channelwise", "oihw"), ("cifar", "rowwise", "hwio"), ("mnist", "columnwise", None),
+                                                   ("imagenette", "channelwise", "oihw")])
+def test_leaf_mode_equals_the_autograd_node(dev, config, orient, storage):
+    """FakeQuantBatch(autograd=False) -- fake-quantised tensors as leaves, finish_backward() after the backward pass (the trainer's
+    form) -- gives the outputs, dP and ds of the one-node autograd form bit for bit; where a parameter already holds a gradient
+    (a regulariser's, a data-parallel bucket view) dP is ADDED to it, as AccumulateGrad would."""
+    import learned_quantization_amd as lq
+    res = {}
+    for autograd in (True, False):
+        m = _model(dev, config, orient, value=1e-4, kernel_storage=storage)
+        batch = lq.FakeQuantBatch(m, hwio_out=False, autograd=autograd)
+        g = torch.Generator(device=dev).manual_seed(33)
+        outs = batch.quantize_all()
+        consumed, dys = [], []
+        for l in lq.custom_layers_of(m):                       # what the layers consume: the companion where there is one
+            w, qb = l.quantized_parameters()
+            for o in (w, qb):
+                if o is not None:
+                    consumed.append(o)
+                    dys.append(torch.randn(tuple(o.shape), device=dev, generator=g) * 1e-3)
+        pre = {}
+        if config == "imagenette":                             # a gradient that is already there (every third parameter)
+            for k, e in enumerate(batch.entries):
+                if k % 3 == 0:
+                    e.param.grad = torch.full_like(e.param.data, 0.25)
+                    pre[k] = True
+        torch.autograd.backward(consumed, dys)
+        if not autograd:
+            batch.finish_backward()
+        res[autograd] = ([o.detach().clone() for o in outs], [e.param.grad.detach().clone() for e in batch.entries],
+                         [e.nested.scale.grad.detach().clone() for e in batch.entries])
+    for what, a, b in zip(("out", "dP", "ds"), res[True], res[False]):
+        for i, (ta, tb) in enumerate(zip(a, b)):
+            assert torch.equal(ta, tb), f"tensor {i}: {what}"
+    assert any(float(t.abs().max()) > 0 for t in res[False][2])
+
+
+def test_leaf_mode_finish_backward_belongs_to_leaf_mode(dev):
+    import learned_quantization_amd as lq
+    b = lq.FakeQuantBatch(_model(dev, "mnist", "rowwise"))
+    with pytest.raises(RuntimeError, match="autograd=False"):
+        b.finish_backward()
