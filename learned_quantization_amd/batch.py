@@ -28,7 +28,8 @@ from .layers import CustomDenseLayer, _ConvBase, custom_layers_of
 
 
 class _Entry:
-    __slots__ = ("layer", "slot", "param", "nested", "out", "ds", "m", "v", "desc", "out_oihw", "dp", "conv", "shape")
+    __slots__ = ("layer", "slot", "param", "nested", "out", "ds", "m", "v", "desc", "out_oihw", "dp", "conv", "shape", "pstride", "pdev",
+                 "nq")
 
 
 class FakeQuantBatch:
@@ -73,6 +74,9 @@ class FakeQuantBatch:
                     raise ValueError("parameters must be dense (contiguous, or a permutation of a contiguous array)")
                 e.out = torch.empty_like(param.data)
                 e.shape = tuple(param.shape)
+                e.pstride = tuple(param.data.stride())
+                e.pdev = param.device
+                e.nq = nested.penalty_threshold is not None
                 # write straight into an existing gradient buffer (e.g. a DataParallel bucket view) when there is one
                 g = nested.scale.grad
                 if g is not None and g.is_contiguous():
@@ -243,6 +247,27 @@ class FakeQuantBatch:
             return dps
         keep = []
         gathered = set()
+        if not batch._oihw_idx:
+            # no companions (kernels stored OIHW, dense models): the per-step host work is one pass of cheap checks -- this loop runs
+            # every eager step for every tensor (tools/bench_weights.py us_per_step_batched_leaves)
+            ptrs = batch._ptrs
+            f32 = torch.float32
+            for i, e in enumerate(batch.entries):
+                d = dys[i]
+                if d is None:
+                    d = torch.zeros_like(e.param.data)
+                elif d.dtype is not f32 or d.shape != e.shape or d.stride() != e.pstride or d.device != e.pdev:
+                    d = _hip.require_device_f32(d, "dy", like=e.param.data)      # the full checks, a relayout where needed
+                if e.nq and e.nested.scale.grad is not None and not batch._external_grads:
+                    raise RuntimeError("FakeQuantBatch: scale gradients must be None before backward "
+                                       "(gradient accumulation over several backward passes is not supported in batched mode)")
+                keep.append(d)
+                ptrs[i] = d.data_ptr()
+            batch._scale_grad_call(False)
+            for e in batch.entries:
+                if e.nq:
+                    e.nested.scale.grad = e.ds                     # written in place by the kernel: no accumulate launch
+            return keep
         for i, e in enumerate(batch.entries):
             d = dys[i]
             if d is None and i in batch._oihw_pos and dys[batch._oihw_pos[i]] is not None:

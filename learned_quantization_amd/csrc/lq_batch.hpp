@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
             const uint32_t nbx = (uint32_t)t.nbx;
             const uint32_t by = b / nbx, bx = b - by * nbx;
             if (t.col_variant >= 4) {
-                if (t.fg.finner >= 2u) col_frag_tile_body<OP, LQ_BATCH_U2, 2, LQ_BATCH_PIPE>(p, (uint32_t)t.C, (uint32_t)t.rps, bx, by, t.fg, reinterpret_cast<Acc*>(smem));
+                if (LQ_BATCH_GF2 && t.fg.finner >= 2u) col_frag_tile_body<OP, LQ_BATCH_U2, 2, LQ_BATCH_PIPE>(p, (uint32_t)t.C, (uint32_t)t.rps, bx, by, t.fg, reinterpret_cast<Acc*>(smem));
                 else col_frag_tile_body<OP, LQ_BATCH_U, 4, LQ_BATCH_PIPE>(p, (uint32_t)t.C, (uint32_t)t.rps, bx, by, t.fg, reinterpret_cast<Acc*>(smem));
             }
             else col_tile_body<OP, 1, 0>(p, t.C, t.rps, (int64_t)bx, (int64_t)by, reinterpret_cast<Acc*>(smem));
@@ -253,26 +253,42 @@ __global__ __launch_bounds__(kBlock) void k_batch_adam(const AdamTask* __restric
 //     other forms bit for bit for lambda < 4e-4, within an ulp of the fp32 mean above.
 // The emitting thread fetches the scale's Adam state BEFORE it walks the partials, so that after the reduction only arithmetic
 // and three stores remain.
-struct FinBlock {
-    uint32_t task;        // bit 31: wide form; bit 30: column form; bit 29: fragment form (lq_batch_cols.hpp)
-    uint32_t g0;          // first group of this block within the task
+// One record per finalize block holds EVERYTHING the block needs (round 4): with a (task, first group) pair the block first fetched
+// its pair, then -- a dependent trip to the L2 -- the task's geometry and pointers, and only then could issue the loads of the
+// partials and of the Adam state; the launch is a chain of such trips (profiles/r04: 5.0 us for 1 MB of partials).
+struct FinRec {
+    uint32_t form;        // 0: wave form, 1: wide form, 2: column form, 3: fragment form (lq_batch_cols.hpp)
+    uint32_t g0;          // first group of this block within its task
+    uint32_t G;           // groups of the task
+    float lam;            // FinT<OP_BWD>::emit: -|tanh(lambda)| where no element voted
+    int64_t ws_off, np_pad;               // the task's slice of the workspace (uint32 words), padded partial count
+    int64_t gstride, n1, stride1, n2;     // partial geometry (lq_traverse.hpp FinGeom); fragment form: n1 row blocks
+    FragGeom fg;
+    double count;         // elements per group
+    float* ds;
+    float* am;            // Adam moments of the scale, or NULL
+    float* av;
+    float* s;
+    float amin;
+    uint32_t pad;
 };
+static_assert(sizeof(FinRec) == 128, "one record = two 64-byte scalar loads");
 
 template <int OP>
-__global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict__ tasks, const FinBlock* __restrict__ blocks, uint32_t* ws,
-                                                          AdamHyper ah) {
+__global__ __launch_bounds__(256) void k_batch_finalize_t(const FinRec* __restrict__ recs, uint32_t* ws, AdamHyper ah) {
     using O = OpT<OP>;
     static_assert(O::kStdMerge, "wave-per-group finalize needs the DPP merge (no block barrier)");
     __shared__ AccW col_tot[256];
-    const FinBlock fb = blocks[blockIdx.x];
-    const bool wide = (fb.task >> 31) != 0, cols = ((fb.task >> 30) & 1u) != 0, frag = ((fb.task >> 29) & 1u) != 0;
-    const Task& t = tasks[fb.task & 0x1fffffffu];
-    Params p = t.p;
+    const FinRec& t = recs[blockIdx.x];
+    const bool wide = t.form == 1u, cols = t.form == 2u, frag = t.form == 3u;
+    Params p;
+    p.lam = t.lam;
+    p.G = (int64_t)t.G;
     p.pa = ws + t.ws_off;
     p.pb = p.pa + t.np_pad;
     p.pc = reinterpret_cast<double*>(p.pb + t.np_pad);
     FinGeom f;
-    f.groups = p.G;
+    f.groups = (int64_t)t.G;
     f.gstride = t.gstride;
     f.n1 = t.n1;
     f.stride1 = t.stride1;
@@ -285,33 +301,33 @@ __global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict
     if (cols || frag) {                       // finalize_cols_body (lq_traverse.hpp): 64 / n2 groups per block, whole partial rows;
                                               // finalize_frag_body (lq_batch_cols.hpp): fg.gpb groups per block, one or two fragments each
         const int gpb = frag ? (int)t.fg.gpb : 64 / (int)t.n2;
-        const int64_t gp = (int64_t)fb.g0 + threadIdx.x;                      // the group this thread will hold (threads < gpb)
-        const bool update = ah.on && t.am && (int)threadIdx.x < gpb && gp < p.G;
+        const int64_t gp = (int64_t)t.g0 + threadIdx.x;                       // the group this thread will hold (threads < gpb)
+        const bool update = ah.on && t.am && (int)threadIdx.x < gpb && gp < (int64_t)t.G;
         AdamCoef c;
         float mi = 0.f, vi = 0.f, w = 0.f;
         if (update) {
             c = adam_coef(ah);
             mi = t.am[gp];
             vi = t.av[gp];
-            w = t.p.s[gp];
+            w = t.s[gp];
         }
         int64_t g;
         AccW acc;
-        const bool holds = frag ? finalize_frag_body<OP>(p, t.fg, t.n1, p.G, fb.g0, col_tot, g, acc)
-                                : finalize_cols_body<OP>(p, f, (int64_t)fb.g0, col_tot, g, acc);
+        const bool holds = frag ? finalize_frag_body<OP>(p, t.fg, t.n1, (int64_t)t.G, t.g0, col_tot, g, acc)
+                                : finalize_cols_body<OP>(p, f, (int64_t)t.g0, col_tot, g, acc);
         if (holds) {
             const float dsg = FinT<OP>::emit(p, f, g, acc);
             if (update) {
                 adam_value(ah, c, dsg, mi, vi, w, t.amin);
                 t.am[g] = mi;
                 t.av[g] = vi;
-                const_cast<float*>(t.p.s)[g] = w;
+                t.s[g] = w;
             }
         }
         return;
     }
-    const int64_t g = (int64_t)fb.g0 + (wide ? 0 : (int64_t)(threadIdx.x >> 6));
-    if (g >= p.G) return;                    // wave-uniform, wave form only (it has no block barrier)
+    const int64_t g = (int64_t)t.g0 + (wide ? 0 : (int64_t)(threadIdx.x >> 6));
+    if (g >= (int64_t)t.G) return;           // wave-uniform, wave form only (it has no block barrier)
     const int tid = wide ? (int)threadIdx.x : (int)(threadIdx.x & 63);
     // the thread that will emit ds[g]: lane 63 of a one-wave finalize, thread 0 of the wide one
     const bool update = ah.on && t.am && tid == (wide ? 0 : 63);
@@ -321,14 +337,14 @@ __global__ __launch_bounds__(256) void k_batch_finalize_t(const Task* __restrict
         c = adam_coef(ah);
         mi = t.am[g];
         vi = t.av[g];
-        w = t.p.s[g];
+        w = t.s[g];
     }
     const float dsg = wide ? finalize_block_body<OP, 256>(p, f, g, tid) : finalize_block_body<OP, 64>(p, f, g, tid);
     if (update) {
         adam_value(ah, c, dsg, mi, vi, w, t.amin);
         t.am[g] = mi;
         t.av[g] = vi;
-        const_cast<float*>(t.p.s)[g] = w;
+        t.s[g] = w;
     }
 }
 

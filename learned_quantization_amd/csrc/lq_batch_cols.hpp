@@ -29,13 +29,19 @@ namespace lq {
 //  bit for bit there; above, the f64 sums differ below 2^-50 relative as between any two traversals.
 // ------------------------------------------------------------------------------------------
 #ifndef LQ_BATCH_U
-#define LQ_BATCH_U 2          // rows per wave and stage (float4 of each stream per lane), per-column form
+#define LQ_BATCH_U 4          // rows per wave and stage (float4 of each stream per lane), per-column form
 #endif
 #ifndef LQ_BATCH_U2
-#define LQ_BATCH_U2 2         // the same for the two-group form
+#define LQ_BATCH_U2 4         // the same for the two-group form
 #endif
 #ifndef LQ_BATCH_PIPE
-#define LQ_BATCH_PIPE 1       // 1: the loads of the next stage are issued before the current stage is consumed (two register sets)
+#define LQ_BATCH_PIPE 0       // 1: the loads of the next stage are issued before the current stage is consumed (two register sets)
+#endif
+#ifndef LQ_BATCH_GF2
+#define LQ_BATCH_GF2 1        // 0: the per-column form for every `inner`
+#endif
+#ifndef LQ_BATCH_NT
+#define LQ_BATCH_NT 0         // 1: nontemporal loads
 #endif
 
 // GF = 4: a context and an accumulator per COLUMN of the lane's float4 (any `inner`; the only form for inner == 1, where the four
@@ -81,8 +87,8 @@ __device__ __forceinline__ void col_frag_tile_body(const Params& p, uint32_t C, 
             const bool in = r + 4u * (uint32_t)u < r1;     // scalar; beyond the block: the block's last row again (loads stay unconditional)
             const char* const qp = in ? rp + (size_t)u * step4 : lastP;
             const char* const qd = in ? rd + (size_t)u * step4 : lastD;
-            x[u] = *reinterpret_cast<const float4*>(qp + voff);
-            d[u] = *reinterpret_cast<const float4*>(qd + voff);
+            x[u] = load4<LQ_BATCH_NT>(reinterpret_cast<const float*>(qp + voff));
+            d[u] = load4<LQ_BATCH_NT>(reinterpret_cast<const float*>(qd + voff));
         }
     };
     // the lane's scales first -- a few words, cache-resident -- then the first stage: vector loads return in order (one vmcnt), so

@@ -1413,7 +1413,8 @@ struct lq_task_table {                    // one device-resident task table
     lq::Task* d = nullptr;
     uint32_t* prefix_d = nullptr;         // [n] first block of every task, then [n] first group
     uint16_t* block_task_d = nullptr;     // [blocks] task of every traversal block
-    lq::FinBlock* fin_blocks_d = nullptr; // [fin_blocks] task and first group of every finalize block (scale-gradient tables)
+    lq::FinRec* fin_blocks_d = nullptr;   // [fin_blocks] one self-contained record per finalize block (scale-gradient tables)
+    std::vector<lq::FinRec> fin_h;        // host copy: the Adam-state pointers are filled in by lq_batch_create before the upload
     uint32_t fin_blocks = 0;
     uint32_t blocks = 0, groups = 0;
     bool has_tile = false;                // some task runs the conv tile (needs the tile kernel's LDS)
@@ -1659,20 +1660,38 @@ static int finish_table(lq_task_table& tb, bool bwd) {
         // finalize blocks: column traversals (one partial per (row block, column), a group's partials `C` words apart) get a
         // block per floor(64 / inner) groups that reads contiguous runs of the rows of partials; otherwise four groups per block (a wave each)
         // where a group has at most 256 partials, else a block per group
-        std::vector<FinBlock> fb;
+        std::vector<FinRec>& fb = tb.fin_h;
+        fb.clear();
         for (size_t k = 0; k < n; ++k) {
             const Task& t = tb.h[k];
             const bool frag = t.fg.gpb != 0;                                                  // lq_batch_cols.hpp: fragments of fg.gpb groups per block
             const bool cols = !frag && finalize_cols_ok(t.p.G, t.gstride, t.n1, t.stride1, t.n2);      // the rule of the single-tensor finalize
             const bool wide = !frag && !cols && t.n1 * t.n2 > 256;
             const int64_t per = frag ? (int64_t)t.fg.gpb : (cols ? 64 / t.n2 : (wide ? 1 : 4));
-            const uint32_t flag = frag ? 0x20000000u : (cols ? 0x40000000u : (wide ? 0x80000000u : 0u));
-            for (int64_t g = 0; g < t.p.G; g += per) fb.push_back({(uint32_t)k | flag, (uint32_t)g});
+            FinRec r;
+            memset(&r, 0, sizeof(r));
+            r.form = frag ? 3u : (cols ? 2u : (wide ? 1u : 0u));
+            r.G = (uint32_t)t.p.G;
+            r.lam = t.p.lam;
+            r.ws_off = t.ws_off;
+            r.np_pad = t.np_pad;
+            r.gstride = t.gstride;
+            r.n1 = t.n1;
+            r.stride1 = t.stride1;
+            r.n2 = t.n2;
+            r.fg = t.fg;
+            r.count = t.count;
+            r.ds = t.ds;
+            r.s = const_cast<float*>(t.p.s);
+            r.pad = (uint32_t)k;                       // table position of the task: fill_fin_state() finds its Adam state through it
+            for (int64_t g = 0; g < t.p.G; g += per) {
+                r.g0 = (uint32_t)g;
+                fb.push_back(r);
+            }
         }
         if (fb.size() > 0x7fffffffull) return fail(LQ_EINVAL, "lq_batch_create: too many groups");
         tb.fin_blocks = (uint32_t)fb.size();
-        e = hipMalloc(&tb.fin_blocks_d, fb.size() * sizeof(FinBlock));
-        if (e == hipSuccess) e = hipMemcpy(tb.fin_blocks_d, fb.data(), fb.size() * sizeof(FinBlock), hipMemcpyHostToDevice);
+        e = hipMalloc(&tb.fin_blocks_d, fb.size() * sizeof(FinRec));
     }
     if (e == hipSuccess) e = hipMalloc(&tb.d, n * sizeof(Task));
     if (e != hipSuccess) return fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
@@ -1682,6 +1701,15 @@ static int finish_table(lq_task_table& tb, bool bwd) {
 static int upload_table(lq_task_table& tb) {
     if (tb.h.empty()) return LQ_OK;
     hipError_t e = hipMemcpy(tb.d, tb.h.data(), tb.h.size() * sizeof(Task), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !tb.fin_h.empty()) {
+        for (FinRec& r : tb.fin_h) {                   // Adam state of the task (set after finish_table ordered the tasks)
+            const Task& t = tb.h[r.pad];
+            r.am = t.am;
+            r.av = t.av;
+            r.amin = t.amin;
+        }
+        e = hipMemcpy(tb.fin_blocks_d, tb.fin_h.data(), tb.fin_h.size() * sizeof(FinRec), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) return fail(LQ_EHIP, "lq_batch_create: %s", hipGetErrorString(e));
     return LQ_OK;
 }
@@ -1923,8 +1951,7 @@ static int batch_scale_grad(const lq_batch* b, const float* const* dy, void* ws,
                            (uint32_t*)ws, pk, 1, cf);
     int rc = check_hip("batch scale-grad launch");
     if (rc) return rc;
-    hipLaunchKernelGGL((k_batch_finalize_t<OP_BWD>), dim3(tb.fin_blocks), dim3(256), 0, (hipStream_t)stream, tb.d, tb.fin_blocks_d,
-                       (uint32_t*)ws, ah);
+    hipLaunchKernelGGL((k_batch_finalize_t<OP_BWD>), dim3(tb.fin_blocks), dim3(256), 0, (hipStream_t)stream, tb.fin_blocks_d, (uint32_t*)ws, ah);
     return check_hip("batch finalize launch");
 }
 

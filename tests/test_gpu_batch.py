@@ -80,6 +80,8 @@ def test_batched_training_matches_unbatched(dev, tmp_path):
             tr.scale_opt.zero_grad(set_to_none=True)
             loss = tr.loss(y, tr.model(x))
             loss.backward()
+            if tr.batch is not None:
+                tr.batch.finish_backward()      # the trainer's batch hands out leaves (FakeQuantBatch(autograd=False))
             tr.opt.step()
             tr.scale_opt.step()
             losses.append(float(loss))
