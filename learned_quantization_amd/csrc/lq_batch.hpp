@@ -29,9 +29,9 @@ struct Task {
     int pad2;
     float* mb;                // batch-owned per-group max(|P|/s)      (MaxBin penalty)
     uint32_t* ties;           // batch-owned per-group tie counts
-    int mode, vec, lpr_log2, pad0;
+    int mode, vec, lpr_log2, ru;   // ru: float4 per thread and stream of a row-stream unit (1, 2 or 4: units of 1024 / 2048 / 4096 elements)
     int64_t R, L, nc;         // row modes (block size 256)
-    int64_t C, rps, nbx;      // column mode (rps = rows per block, nbx = blocks along the columns)
+    int64_t C, rps, nbx;      // column mode (rps = rows per block, nbx = blocks along the columns; col_variant 6: rps = number of blocks)
     int col_variant, pad1;
     FragGeom fg;              // scale-gradient tables, float4 column tiles: partial layout of lq_batch_cols.hpp (fg.F == 0: generic layout)
     int64_t np_pad;           // padded partial count; this task's workspace slice is 4 * np_pad words (u32, u32, f64)
@@ -72,7 +72,7 @@ template <int OP>
 __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restrict__ tasks, const uint16_t* __restrict__ block_task, int ntasks,
                                                            uint32_t* ws, PtrPack pk, int use_pack, CoefPack cf) {
     // one LDS scratch: the column traversal's accumulators, or the transposed tile of a conv kernel
-    constexpr int kColBytes = OpT<OP>::kReduce ? kBlock * 4 * (int)sizeof(Acc) : 16;
+    constexpr int kColBytes = OpT<OP>::kReduce ? (OP == OP_BWD ? kColLdsAcc : kBlock * 4) * (int)sizeof(Acc) : 16;      // OP_BWD: + the periodic form's second stage
     constexpr int kTileBytes = OP == OP_FWD_PERM ? kCtLdsWordsFwd * 4 : (OP == OP_BWD_PERM ? kCtLdsWordsBwd * 4 : 16);
     __shared__ __align__(16) unsigned char smem[kColBytes > kTileBytes ? kColBytes : kTileBytes];
     LQ_TRACE(0);
@@ -112,8 +112,20 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
         const uint32_t nc = (uint32_t)t.nc;
         const uint32_t row = b / nc, ck = b - row * nc;
         const int64_t g = (int64_t)(row % (uint32_t)p.G);
-        if (t.vec) row_stream_body<OP, 4, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
-        else row_stream_body<OP, 1, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
+        if (t.vec) {
+            // long rows (per-tensor scales: the whole tensor is one row) take units of 2048 / 4096 elements in the forward and the
+            // scale-gradient tables: 1024-element blocks are 11 K blocks for the ResNet-18-like set, each paying the head of a block
+            // (block -> task -> first load) for 4 KB per stream
+            if constexpr (OP == OP_FWD || OP == OP_BWD) {
+                if (t.ru == 4) row_stream_body<OP, 4, kBlock, 0, 4>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
+                else if (t.ru == 2) row_stream_body<OP, 4, kBlock, 0, 2>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
+                else row_stream_body<OP, 4, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
+            } else {
+                row_stream_body<OP, 4, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
+            }
+        } else {
+            row_stream_body<OP, 1, kBlock, 0>(p, t.L, t.nc, (int64_t)row, (int64_t)ck, g);
+        }
     } else if (t.mode == 1) {
         if (t.vec) row_small_body<OP, 4>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
         else row_small_body<OP, 1>(p, t.R, (int)t.L, t.lpr_log2, (int64_t)b);
@@ -121,6 +133,8 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
         // scale-gradient pass: float4 tiles run the fragment form (lq_batch_cols.hpp); the generic float4 tile is not instantiated here
         if (t.col_variant == 0) {
             col_small_body<OP>(p, (int)t.C, t.rps, (int64_t)b, reinterpret_cast<Acc*>(smem));
+        } else if (t.col_variant == 6) {       // C <= 64: the periodic float4 stream (a thread's four columns never change), t.rps blocks
+            col_periodic4_body<OP, 0>(p, (int)t.C, t.rps, (int64_t)b, reinterpret_cast<Acc*>(smem));
         } else {
             const uint32_t nbx = (uint32_t)t.nbx;
             const uint32_t by = b / nbx, bx = b - by * nbx;
@@ -131,7 +145,8 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
             else col_tile_body<OP, 1, 0>(p, t.C, t.rps, (int64_t)bx, (int64_t)by, reinterpret_cast<Acc*>(smem));
         }
     } else {
-        col_body<OP, false>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b, t.n1, reinterpret_cast<Acc*>(smem));
+        // (the periodic float4 stream, variant 6, is planned for the forward and the scale-gradient tables only)
+        col_body<OP, OP == OP_FWD>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b, t.rps, reinterpret_cast<Acc*>(smem));
     }
 #ifdef LQ_DEV_KNOBS
     __syncthreads();

@@ -1521,6 +1521,17 @@ static void batch_rows_per_block(Plan& pl, int64_t outer, double w) {
     pl.ysplit = ceil_div(outer, rb);
 }
 
+// Narrow column matrices (C <= 64: row-wise / column-wise scales of a conv kernel stored OIHW are [co ci][kh kw] and [co ci kh][kw],
+// groups of period 9 and 3) as a periodic float4 stream (lq_traverse.hpp col_periodic4_body): `nblk` blocks, a multiple of C, so that
+// a thread's four columns never change; about `w` elements per block.  The scalar form it replaces in the batch reads 4 bytes per
+// lane (col_small_body: 252 bytes per wave and load for C = 9).
+static int64_t batch_periodic_blocks(int64_t C, double elements, double w) {
+    int64_t k = (int64_t)(elements / w / (double)C + 0.5);
+    if (k < 1) k = 1;
+    return C * k;
+}
+constexpr double kBatchPeriodicMin = 32768.0;      // elements from which a C <= 64 task of the batch takes the periodic form
+
 static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, bool allow_tile, lq_task_table& tb, double batch_w = 0.0) {
     memset(&t, 0, sizeof(t));
     Plan pl = make_plan(d.outer, d.G, d.inner, kBlock);
@@ -1551,7 +1562,7 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, bool allow_tile
         col_variant(pl, d.P, nullptr, bwd ? nullptr : d.out, t.col_variant, t.nbx, false);
         // scale-gradient table of the plain (non-companion) pass: float4 tiles run lq_batch_cols.hpp -- batch-sized row blocks, one
         // partial per (row block, group fragment)
-        if (batch_w > 0.0 && t.col_variant >= 4 && pl.C < (1ll << 30) && d.outer < (1ll << 31)) {
+        if (bwd && batch_w > 0.0 && t.col_variant >= 4 && pl.C < (1ll << 30) && d.outer < (1ll << 31)) {
             batch_rows_per_block(pl, d.outer, batch_w);
             LQ_KNOB(frag, "LQ_TUNE_BATCH_FRAG", 1);    // development: 0 = a partial per column (the generic layout)
             const bool grouped = frag && d.inner > 1 && d.inner <= 64;
@@ -1566,10 +1577,18 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, bool allow_tile
             } else {
                 t.fg.gpb = 0;
             }
-        } else if (batch_w > 0.0 && t.col_variant >= 4) {
+        } else if (bwd && batch_w > 0.0 && t.col_variant >= 4) {
             // a matrix beyond the 32-bit extents of that form (2^30 columns): the scalar column tile, generic layout
             t.col_variant = 1;
             t.nbx = ceil_div(pl.C, 64);
+        } else if (batch_w > 0.0 && t.col_variant == 0 && (double)d.outer * (double)pl.C >= kBatchPeriodicMin && aligned(d.P, 16) &&
+                   (bwd || aligned(d.out, 16))) {
+            t.col_variant = 6;
+            pl.ysplit = batch_periodic_blocks(pl.C, (double)d.outer * (double)pl.C, batch_w);
+            pl.rps = pl.ysplit;                        // variant 6: the block count travels in `rps`
+            t.nbx = 1;
+            pl.np = pl.ysplit * pl.C;                  // one partial per (block, column)
+            pl.n1 = pl.ysplit;
         }
     }
     t.rps = pl.rps;
@@ -1578,9 +1597,23 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, bool allow_tile
         blocks = (int64_t)t.ct.ntc * t.ct.nto;
         t.vec = 1;
     } else if (pl.mode == MODE_ROW_BIG) {
-        blocks = pl.R * pl.nc;
         // float4 path: forward needs P and out 16-byte aligned; backward needs P (dy is checked at every launch)
         t.vec = (aligned(d.P, 16) && (bwd || aligned(d.out, 16))) ? 1 : 0;
+        t.ru = 1;
+        if (batch_w > 0.0 && t.vec && d.conv_co == 0) {
+            // batch-sized units for long rows (forward and scale-gradient tables): 4096 elements where a row has at least two of them
+            const int ru = pl.L >= 8192 ? 4 : (pl.L >= 4096 ? 2 : 1);
+            if (ru > 1) {
+                t.ru = ru;
+                pl.nc = row_chunks(pl.L, (int64_t)kBlock * 4 * ru);
+                pl.np = pl.R * pl.nc;
+                pl.gstride = pl.nc;                    // partial (row o * G + g, chunk c) at (o * G + g) * nc + c
+                pl.stride1 = d.G * pl.nc;
+                pl.n2 = pl.nc;
+                t.nc = pl.nc;
+            }
+        }
+        blocks = pl.R * pl.nc;
     } else if (pl.mode == MODE_ROW_SMALL) {
         t.vec = row_small_vec(pl, d.P, nullptr, bwd ? nullptr : d.out) ? 1 : 0;
         if (t.vec) t.lpr_log2 = row_small_lpr_log2_vec(pl.L);
@@ -1741,6 +1774,11 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
         if (descs[i].lambda == descs[i].lambda && descs[i].outer > 0 && descs[i].G > 0 && descs[i].inner > 0)
             bwd_elements += (double)descs[i].outer * (double)descs[i].G * (double)descs[i].inner;
     const double batch_w = batch_block_elements(bwd_elements);
+    // the forward table keeps make_plan's float4 tiles (its blocks are all resident: 61 VGPRs); `b_fwd_w` only sizes the periodic
+    // streams of narrow column matrices -- and only where no OIHW companion is emitted (OP_FWD; OP_FWD_PERM has no float4 element path)
+    bool any_perm = false;
+    for (int i = 0; i < n; ++i) any_perm = any_perm || descs[i].conv_co > 0;
+    const double b_fwd_w = any_perm ? 0.0 : 8192.0;
     for (int i = 0; i < n && !rc; ++i) {
         const lq_tensor_desc& d = descs[i];
         rc = check_desc(d.outer, d.G, d.inner);
@@ -1757,7 +1795,7 @@ int lq_batch_create(const lq_tensor_desc* descs, int n, lq_batch** out) {
             if (!rc) b->has_perm = true;
         }
         Task t;
-        if (!rc) rc = fill_task(t, d, false, true, b->fwd);
+        if (!rc) rc = fill_task(t, d, false, true, b->fwd, b_fwd_w);
         if (rc) break;
         b->fwd.h.push_back(t);
         b->fwd.index.push_back(i);

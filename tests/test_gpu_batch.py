@@ -31,7 +31,11 @@ def _model(dev, config, orient, mode="nq", value=1e-3, seed=3, kernel_storage=No
 @pytest.mark.parametrize("config,orient", [("mnist", "rowwise"), ("mnist", "columnwise"), ("cifar", "channelwise"),
                                            ("cifar", "rowwise"), ("cifar", "columnwise"), ("cifar", "scalar"),
                                            ("imagenette", "channelwise"), ("resnet50", "channelwise"),
-                                           ("resnet50", "columnwise")])
+                                           ("resnet50", "columnwise"),
+                                           # round 4: conv kernels stored OIHW -- row-wise / column-wise scales are narrow column matrices
+                                           # (periodic float4 stream), per-tensor scales one long row (units of 4096 elements)
+                                           ("imagenette", "rowwise"), ("imagenette", "columnwise"), ("imagenette", "scalar"),
+                                           ("resnet50", "scalar")])
 def test_batch_equals_single_tensor_ops_bitwise(dev, config, orient):
     import learned_quantization_amd as lq
     m = _model(dev, config, orient)
