@@ -48,12 +48,19 @@ namespace lq {
 //         columns are four groups, and for the per-column layout);
 // GF = 2: two contexts and two accumulators per lane (lq_math.hpp Ctx2: inner >= 2 -- four adjacent columns touch at most two
 //         groups), grouped layout only.
-// PIPE:   every block of a batch launch starts at t = 0 and is resident to the end (one round of blocks), so the waves of the whole
-//         chip march in step: all issue a stage's loads, all wait for them -- 34 MB in flight, 5 us at the memory system's rate --
-//         all consume them while the memory system idles, three times over (block timeline of the unpipelined form,
-//         profiles/r04/timelines/: every block alive for 13 of the launch's 17.4 us; math-free it ran 1.2 us faster).  With two
-//         register sets the next stage is in flight while the current one is consumed.  The prefetch is unconditional (row index
-//         clamped): a conditional load leaves a pending-counter state on one path that the compiler waits out on every path.
+// PIPE:   (compile-time experiment, off) the loads of the next stage issued before the current stage is consumed, two register
+//         sets.  Every block of a batch launch starts at t = 0 and is resident to the end -- one round of blocks -- and the
+//         unpipelined launch runs 1.2-1.7 us faster math-free (profiles/r04/experiments/), so overlapping a wave's arithmetic with its
+//         own loads looked like the lever.  Measured (profiles/r04/experiments/pipelined_variants_sweep.jsonl): it is not -- the
+//         ResNet-18-like traversal 17.5 us pipelined against 17.4, the ResNet-50-like one 35.4 against 33.0 (99 VGPRs: four waves
+//         per SIMD instead of five); with one row per stage (72 VGPRs, seven waves) 40.3 us per step against 39.6.  The ISA is
+//         what was intended (stage loads, then s_waitcnt vmcnt(7) .. (4) while the other set is consumed).  Three details of it
+//         are kept because the unpipelined loop needs them too: row addresses are wave-uniform POINTERS carried from stage to
+//         stage (a row * pitch product would be formed per lane with v_mad_u64_u32, in registers that alias loads in flight); the
+//         lane offset is re-materialised as a 32-bit value in the block that issues the loads (instruction selection is per
+//         basic block: only there does it see `uniform base + zext(VGPR)` and emit global_load ... v_off, s[base:base+1]); the
+//         prefetch is unconditional (row clamped) -- a conditional load leaves a pending-counter state on one path that the
+//         compiler waits out on every path.
 template <int OP, int U, int GF, int PIPE>
 __device__ __forceinline__ void col_frag_tile_body(const Params& p, uint32_t C, uint32_t RB, uint32_t bx, uint32_t by, const FragGeom fg,
                                                    Acc* lds) {
