@@ -59,15 +59,28 @@ def control_group(group=None):
         return group if group is not None else dist.group.WORLD
     key = id(group) if group is not None else None
     if key not in _control_groups:
+        import os
+        if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: the host name of a container need not resolve
         ranks = dist.get_process_group_ranks(group) if group is not None else None
-        _control_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+        try:
+            _control_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+        except Exception:                   # no usable gloo transport (the same on every rank of a node): agree over the product group
+            _control_groups[key] = _PRODUCT_GROUP
     return _control_groups[key]
+
+
+_PRODUCT_GROUP = "product-group"      # control_group() could not build a gloo group: decisions travel over the default (RCCL) group
 
 
 def agree(code: int, ctl_group) -> int:
     """MIN over the ranks of an integer decision code: every rank returns the same value."""
     if ctl_group is None:
         return code
+    if ctl_group is _PRODUCT_GROUP:
+        t = torch.tensor([int(code)], dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
     t = torch.tensor([int(code)], dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=ctl_group)
     return int(t.item())

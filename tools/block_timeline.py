@@ -71,6 +71,13 @@ def main():
     for i, e in enumerate(edges[:-1]):
         alive = int(((start <= e) & (end > e)).sum())
         print(f"{e:6.1f} {hs[i]:8d} {he[i]:6d} {alive:8d}")
+    # by block index (tasks occupy contiguous index ranges, heaviest first): when do the blocks of each range end
+    nb = len(t)
+    step = max(1, nb // 16)
+    print("# block range: mean start / mean end / max end (us)")
+    for lo in range(0, nb, step):
+        sl = slice(lo, min(lo + step, nb))
+        print(f"  {lo:5d}-{min(lo + step, nb) - 1:5d}  {start[sl].mean():6.2f} {end[sl].mean():6.2f} {end[sl].max():6.2f}")
     # by block index: which blocks started late
     order = np.argsort(start)
     idx = np.nonzero(used)[0]
