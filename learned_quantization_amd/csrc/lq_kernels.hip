@@ -1412,7 +1412,7 @@ struct lq_task_table {                    // one device-resident task table
     std::vector<int> index;               // table position -> descriptor index (tasks are ordered by work per block)
     lq::Task* d = nullptr;
     uint32_t* prefix_d = nullptr;         // [n] first block of every task, then [n] first group
-    uint16_t* block_task_d = nullptr;     // [blocks] task of every traversal block
+    uint32_t* block_task_d = nullptr;     // [blocks] task of every traversal block (a DWORD each: one scalar load; sub-dword entries are fetched with vector loads)
     lq::FinRec* fin_blocks_d = nullptr;   // [fin_blocks] one self-contained record per finalize block (scale-gradient tables)
     std::vector<lq::FinRec> fin_h;        // host copy: the Adam-state pointers are filled in by lq_batch_create before the upload
     uint32_t fin_blocks = 0;
@@ -1680,15 +1680,15 @@ static int finish_table(lq_task_table& tb, bool bwd) {
     tb.blocks = (uint32_t)bp;
     tb.groups = (uint32_t)gp;
     tb.ws_words = words;
-    std::vector<uint16_t> bt((size_t)bp);
+    std::vector<uint32_t> bt((size_t)bp);
     for (size_t k = 0; k < n; ++k) {
         const uint64_t end = k + 1 < n ? prefix[k + 1] : bp;
-        for (uint64_t b = prefix[k]; b < end; ++b) bt[b] = (uint16_t)k;
+        for (uint64_t b = prefix[k]; b < end; ++b) bt[b] = (uint32_t)k;
     }
     hipError_t e = hipMalloc(&tb.prefix_d, 2 * n * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(tb.prefix_d, prefix.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&tb.block_task_d, bt.size() * sizeof(uint16_t));
-    if (e == hipSuccess) e = hipMemcpy(tb.block_task_d, bt.data(), bt.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&tb.block_task_d, bt.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(tb.block_task_d, bt.data(), bt.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && bwd && gp > 0) {
         // finalize blocks: column traversals (one partial per (row block, column), a group's partials `C` words apart) get a
         // block per floor(64 / inner) groups that reads contiguous runs of the rows of partials; otherwise four groups per block (a wave each)

@@ -384,3 +384,50 @@ def test_leaf_mode_finish_backward_belongs_to_leaf_mode(dev):
     b = lq.FakeQuantBatch(_model(dev, "mnist", "rowwise"))
     with pytest.raises(RuntimeError, match="autograd=False"):
         b.finish_backward()
+
+
+@pytest.mark.parametrize("orient", ["channelwise", "rowwise", "columnwise", "scalar"])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_batch_of_odd_conv_shapes_equals_single_tensor_ops(dev, orient, seed):
+    """The batch's own traversal forms (round 4: fragment column tiles with cut groups, partial last tiles and row blocks shorter than a
+    stage; the periodic float4 stream for narrow column matrices; 2048 / 4096-element units) on conv kernels the models do not have --
+    2x2 ... 5x3 taps, odd channel counts, 3 ... 700 output channels, stored OIHW -- against the single-tensor ops bit for bit
+    (lambda < 4e-4: exact vote sums) and, for the small ones, against the oracle."""
+    import learned_quantization_amd as lq
+    rng = np.random.default_rng(100 + seed)
+    taps = [(3, 3), (1, 1), (2, 2), (1, 3), (3, 1), (2, 3), (3, 5), (5, 3), (1, 2), (4, 4), (5, 5), (7, 7)]
+    lq.reset_layer_names()
+    layers = []
+    for k in range(22):
+        kh, kw = taps[int(rng.integers(len(taps)))]
+        ci = int(rng.choice([3, 4, 7, 12, 20, 28, 33, 40, 64, 100, 128, 172]))
+        co = int(rng.choice([3, 8, 17, 32, 60, 64, 130, 256, 700]))
+        if kh * kw * ci * co > 3_000_000:
+            co = 64
+        l = lq.CustomConv2DLayer(seed=k, penalty_threshold=float(rng.choice([1e-11, 1e-8, 1e-4])), orientation=orient,
+                                 initializer=lq.RandomNormal(seed=1000 * seed + k), filters=co, kernel_size=(kh, kw), strides=(1, 1),
+                                 padding="same", name="c", regularizer=None, input_shape=ci, device=dev, kernel_storage="oihw")
+        with torch.no_grad():
+            l.nested_q_k_layer.scale.copy_(torch.tensor(rng.uniform(1e-3, 1e-2, size=tuple(l.nested_q_k_layer.scale.shape)).astype(np.float32)))
+            l.nested_q_b_layer.scale.fill_(float(rng.uniform(1e-3, 1e-2)))
+        layers.append(l)
+    batch = lq.FakeQuantBatch(layers, hwio_out=False)
+    outs = batch.quantize_all()
+    g = torch.Generator(device=dev).manual_seed(7 + seed)
+    dys = []
+    for o in outs:      # magnitudes over ten decades: votes on both sides of every threshold in use
+        mag = torch.pow(10.0, torch.empty(tuple(o.shape), device=dev).uniform_(-13.0, -3.0, generator=g))
+        dys.append(torch.randn(tuple(o.shape), device=dev, generator=g) * mag)
+    torch.autograd.backward(outs, dys)
+    for e, o, d in zip(batch.entries, outs, dys):
+        tag = f"{tuple(e.param.shape)} {orient} desc {e.desc}"
+        assert torch.equal(o, lq.fq_forward(e.param.data, e.nested.scale.data)), f"{tag}: forward"
+        ds_ref = lq.fq_scale_grad(e.param.data, e.nested.scale.data, d, e.nested.penalty_threshold)
+        assert torch.equal(e.nested.scale.grad, ds_ref), f"{tag}: scale gradient"
+        assert torch.equal(e.param.grad, d), f"{tag}: dP must be dy"
+        if e.param.numel() <= 100000:
+            P, s = e.param.detach().cpu().numpy(), e.nested.scale.detach().cpu().numpy()
+            _, out_o = O.fq_forward(P, s)
+            np.testing.assert_array_equal(o.detach().cpu().numpy(), out_o, err_msg=tag)
+            _, ds_o = O.nq_backward(P, s, e.nested.penalty_threshold, d.cpu().numpy())
+            np.testing.assert_allclose(e.nested.scale.grad.cpu().numpy(), ds_o, rtol=1e-5, atol=0, err_msg=tag)
