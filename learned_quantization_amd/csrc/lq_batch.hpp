@@ -102,23 +102,9 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
     p.pb = p.pa + t.np_pad;
     p.pc = reinterpret_cast<double*>(p.pb + t.np_pad);
     const uint32_t b = blockIdx.x - t.first_block;
-#ifndef LQ_BATCH_PIN
-#define LQ_BATCH_PIN 0        // compile-time experiment (see below), off
-#endif
-    if constexpr (LQ_BATCH_PIN && (OP == OP_FWD || OP == OP_BWD)) {
-        // ONE round of scalar loads for everything the traversal forms read from the task before their first vector load.  Left to
-        // itself the compiler fetches each field where the control flow first needs it -- seven dependent s_load / s_waitcnt
-        // rounds between the block's start and its first data load (block -> task -> mode -> variant -> geometry -> pointers ...),
-        // and in a launch whose blocks all start at t = 0 nothing hides them (round 4).  The empty asm statements only pin the
-        // values to SGPRs here.
-#define LQ_PIN_S(x) asm volatile("" : : "s"(x))
-        LQ_PIN_S(t.mode); LQ_PIN_S(t.col_variant); LQ_PIN_S(t.vec); LQ_PIN_S(t.ru);
-        LQ_PIN_S((uint32_t)t.C); LQ_PIN_S((uint32_t)t.rps); LQ_PIN_S((uint32_t)t.nbx); LQ_PIN_S((uint32_t)t.nc); LQ_PIN_S((uint32_t)t.L);
-        LQ_PIN_S(t.fg.finner); LQ_PIN_S(t.fg.lq); LQ_PIN_S(t.fg.F);
-        LQ_PIN_S(p.P); LQ_PIN_S(p.s); LQ_PIN_S(p.dy); LQ_PIN_S(p.out);
-        LQ_PIN_S((uint32_t)p.outer); LQ_PIN_S((uint32_t)p.G); LQ_PIN_S((uint32_t)p.inner); LQ_PIN_S(p.lam); LQ_PIN_S(p.tmode);
-#undef LQ_PIN_S
-    }
+    // (Tried, round 4: pinning every task field the traversal forms read to SGPRs right here, so that the seven dependent
+    // s_load / s_waitcnt rounds the compiler spreads over the control flow below become one.  32 SGPRs spill to VGPR lanes and the
+    // step is 1.3-2 us SLOWER on all three sets measured -- profiles/r04/experiments/pinned_task_fields.jsonl.)
     if (t.mode == MODE_CONV_TILE) {
         if constexpr (OP == OP_FWD_PERM) {
             conv_tile_fwd(p, t.ct, b, reinterpret_cast<float*>(smem));
