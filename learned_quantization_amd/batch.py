@@ -167,6 +167,7 @@ class FakeQuantBatch:
 
     def _quantize_all_leaves(self):
         _hip.check(_hip.load().lq_batch_forward(self._handle, _hip.stream_ptr(self.device)), "lq_batch_forward")
+        self._awaiting_finish = True
         outs = []
         for lf, lo in zip(self._leaf, self._leaf_o):
             if lf is not None:
@@ -185,6 +186,10 @@ class FakeQuantBatch:
         gives every parameter its ``dP = dy`` (custom_layers.py:118)."""
         if self.autograd:
             raise RuntimeError("finish_backward() belongs to FakeQuantBatch(autograd=False)")
+        if not getattr(self, "_awaiting_finish", False):
+            # a second call would add dP to the parameters' gradients (bucket views) once more
+            raise RuntimeError("finish_backward() without a quantize_all() since the last call: one backward pass per forward")
+        self._awaiting_finish = False
         dys = [None if lf is None else lf.grad for lf in self._leaf] + [self._leaf_o[i].grad for i in self._oihw_idx]
         dps = self._backward_core(dys)
         alias_p, add_to, add_from = [], [], []

@@ -100,7 +100,7 @@ def capture_with_agreement(attempt: Callable[[], None], ctl_group, health_check:
         code = CAPTURED
     except CaptureRefused as e:
         code, err = REFUSED, e
-    except BaseException as e:              # noqa: BLE001 -- reported to the other ranks first, then re-raised
+    except Exception as e:                  # noqa: BLE001 -- reported to the other ranks first, then re-raised
         code, err = FATAL, e
     agreed = agree(code, ctl_group)
     if code == FATAL:
@@ -115,7 +115,7 @@ def capture_with_agreement(attempt: Callable[[], None], ctl_group, health_check:
     if health_check is not None:
         try:
             health_check()
-        except BaseException as e:          # noqa: BLE001
+        except Exception as e:              # noqa: BLE001
             ok, herr = FATAL, e
     if agree(ok, ctl_group) != CAPTURED:
         raise RuntimeError("the collective could not be recorded into a hipGraph on every rank and the communicator does not answer "

@@ -384,6 +384,12 @@ def test_leaf_mode_finish_backward_belongs_to_leaf_mode(dev):
     b = lq.FakeQuantBatch(_model(dev, "mnist", "rowwise"))
     with pytest.raises(RuntimeError, match="autograd=False"):
         b.finish_backward()
+    b = lq.FakeQuantBatch(_model(dev, "mnist", "rowwise"), autograd=False)
+    outs = b.quantize_all()
+    torch.autograd.backward(outs, [torch.ones_like(o) * 1e-3 for o in outs])
+    b.finish_backward()
+    with pytest.raises(RuntimeError, match="one backward pass per forward"):       # a second call would add dP once more
+        b.finish_backward()
 
 
 @pytest.mark.parametrize("orient", ["channelwise", "rowwise", "columnwise", "scalar"])
