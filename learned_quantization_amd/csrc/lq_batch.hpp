@@ -147,6 +147,17 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
             }
             else col_tile_body<OP, 1, 0>(p, t.C, t.rps, (int64_t)bx, (int64_t)by, reinterpret_cast<Acc*>(smem));
         }
+#ifndef LQ_BATCH_FWD_TILE
+#define LQ_BATCH_FWD_TILE 0   // compile-time experiment: the forward's float4 column tiles with the addressing of lq_batch_cols.hpp
+#endif
+    } else if constexpr (LQ_BATCH_FWD_TILE && OP == OP_FWD) {
+        if (t.col_variant == 4 && !p.q && t.C < (1ll << 30) && p.outer < (1ll << 31)) {
+            const uint32_t nbx = (uint32_t)t.nbx;
+            const uint32_t by = b / nbx, bx = b - by * nbx;
+            col_fwd_tile_body<4>(p, (uint32_t)t.C, (uint32_t)t.rps, bx, by);
+        } else {
+            col_body<OP, true>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b, t.rps, reinterpret_cast<Acc*>(smem));
+        }
     } else {
         // (the periodic float4 stream, variant 6, is planned for the forward and the scale-gradient tables only)
         col_body<OP, OP == OP_FWD>(p, t.C, t.rps, t.nbx, t.col_variant, (int64_t)b, t.rps, reinterpret_cast<Acc*>(smem));

@@ -252,6 +252,76 @@ __device__ __forceinline__ void col_frag_tile_body(const Params& p, uint32_t C, 
     }
 }
 
+// The forward of the same tiles (multi-tensor batch, OP_FWD, float4 tiles): the addressing of col_frag_tile_body -- wave-uniform row
+// pointers, a 32-bit lane offset, the lane's scales requested before the first stage's data -- with one context per column (the
+// forward reduces nothing: no accumulators, no LDS).  `out` has the parameter's layout.
+template <int U>
+__device__ __forceinline__ void col_fwd_tile_body(const Params& p, uint32_t C, uint32_t RB, uint32_t bx, uint32_t by) {
+    using O = OpT<OP_FWD>;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t col0 = (bx * 64u + lane) * 4u;
+    const bool active = col0 < C;
+    uint32_t voff = (active ? col0 : 0u) * 4u;
+    const uint32_t outer = (uint32_t)p.outer;
+    const uint32_t r0 = by * RB;
+    const uint32_t r1 = (r0 + RB < outer) ? r0 + RB : outer;
+    const size_t row_bytes = (size_t)C * 4u;
+    const char* const Pb = reinterpret_cast<const char*>(p.P);
+    char* const Ob = reinterpret_cast<char*>(p.out);
+    const size_t step4 = 4u * row_bytes;
+    const char* const lastP = Pb + (size_t)(r1 - 1u) * row_bytes;
+    const uint32_t inner = (uint32_t)p.inner;
+    const uint32_t cg = active ? col0 : 0u;
+    const uint32_t g0 = cg / inner, k0 = cg - g0 * inner;
+    float sv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t g = g0, kk = k0 + (uint32_t)k;
+        while (kk >= inner) {
+            kk -= inner;
+            ++g;
+        }
+        sv[k] = p.s[g];
+    }
+    float4 x[U];
+    auto load_stage = [&](uint32_t r, const char* rp) {
+        asm volatile("" : "+v"(voff));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool in = r + 4u * (uint32_t)u < r1;
+            const char* const qp = in ? rp + (size_t)u * step4 : lastP;
+            x[u] = *reinterpret_cast<const float4*>(qp + voff);
+        }
+    };
+    uint32_t r = r0 + w;
+    const char* rp = Pb + (size_t)r * row_bytes;
+    char* ro = Ob + (size_t)r * row_bytes;
+    const size_t stage = (size_t)U * step4;
+    load_stage(r, rp);
+    __builtin_amdgcn_sched_barrier(0);
+    Ctx ctx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ctx[k] = O::ctx_of(p, sv[k]);
+    if (r >= r1) return;
+    Acc* const none = nullptr;
+    for (;;) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r + 4u * (uint32_t)u < r1) {               // scalar condition
+                const int64_t i = (int64_t)(r + 4u * (uint32_t)u) * C + col0;
+                const float4 o = O::elem4c(p, ctx, i, x[u], x[u], none);
+                if (active) *reinterpret_cast<float4*>(ro + (size_t)u * step4 + voff) = o;
+            }
+        }
+        r += 4u * U;
+        rp += stage;
+        ro += stage;
+        if (r >= r1) break;
+        load_stage(r, rp);
+    }
+}
+
 // Finalize of that layout: the partials are a matrix [n1 row blocks][F fragments].  A 256-thread block takes `gpb` consecutive groups:
 // lane l of every wave owns fragment column c0 + l (every load a contiguous run of a partial row), wave w walks row blocks
 // w, w + 4, ...; the four waves' totals meet in LDS and thread t < gpb merges the one or two fragments of group g0 + t in a

@@ -198,9 +198,10 @@ class DataParallel:
     backward passes under ``with dp.no_sync():`` (gradients accumulate in the bucket, nothing is exchanged); a second
     backward that would hit an already exchanged bucket raises instead of silently leaving the replicas diverged.
 
-    With the multi-tensor batch (``FakeQuantBatch``) every dP flows through ONE autograd node at the very end of the
-    backward pass, so buckets that hold quantised parameters or scales complete last and nothing of their exchange
-    overlaps; buckets of the ordinary layers (BN, plain Dense) still do.
+    With the multi-tensor batch (``FakeQuantBatch``) every dP is handed over at the very end of the backward pass -- by ONE
+    autograd node, or (``autograd=False``) by ``finish_backward()`` after it -- so buckets that hold quantised parameters or
+    scales complete last and nothing of their exchange overlaps (``attach_batch`` holds them for ``exchange()``); buckets of
+    the ordinary layers (BN, plain Dense) still do.
 
     mode "B": the nested layers are told to skip their local scale gradient in backward (it would be discarded);
     ``sync_gradients`` recomputes every ds from the all-reduced P.grad -- through ``batch.scale_grads_from_param_grads()``
