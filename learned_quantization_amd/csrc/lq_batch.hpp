@@ -148,8 +148,8 @@ __global__ __launch_bounds__(kBlock) void k_batch_traverse(const Task* __restric
             else col_tile_body<OP, 1, 0>(p, t.C, t.rps, (int64_t)bx, (int64_t)by, reinterpret_cast<Acc*>(smem));
         }
 #ifndef LQ_BATCH_FWD_TILE
-#define LQ_BATCH_FWD_TILE 0   // compile-time experiment: the forward's float4 column tiles with the addressing of lq_batch_cols.hpp
-#endif
+#define LQ_BATCH_FWD_TILE 1   // the forward's float4 column tiles with the addressing of lq_batch_cols.hpp (0: the generic col_tile_body):
+#endif                        // forward launch 16.4 -> 15.8 us, step -1.0 us on both ResNet sets (profiles/r04/experiments/forward_tile_addressing.jsonl)
     } else if constexpr (LQ_BATCH_FWD_TILE && OP == OP_FWD) {
         if (t.col_variant == 4 && !p.q && t.C < (1ll << 30) && p.outer < (1ll << 31)) {
             const uint32_t nbx = (uint32_t)t.nbx;

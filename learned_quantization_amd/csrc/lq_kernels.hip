@@ -1577,6 +1577,10 @@ static int fill_task(Task& t, const lq_tensor_desc& d, bool bwd, bool allow_tile
             } else {
                 t.fg.gpb = 0;
             }
+        } else if (!bwd && batch_w > 0.0 && t.col_variant >= 4) {
+            // forward tiles keep make_plan's row blocks (16-32 rows: 1968 blocks for the ResNet-18-like set, all resident at 62 VGPRs)
+            LQ_KNOB(fw, "LQ_TUNE_BATCH_FWD_W", 0);     // development: elements per block of the forward's tiles
+            if (fw > 0) batch_rows_per_block(pl, d.outer, (double)fw);
         } else if (bwd && batch_w > 0.0 && t.col_variant >= 4) {
             // a matrix beyond the 32-bit extents of that form (2^30 columns): the scalar column tile, generic layout
             t.col_variant = 1;
