@@ -135,6 +135,14 @@ class FakeQuantBatch:
             # looks at their values, only routes gradients to them)
             self._leaf = [None if e.out is None else e.out.detach().requires_grad_(True) for e in self.entries]
             self._leaf_o = [None if e.out_oihw is None else e.out_oihw.detach().requires_grad_(True) for e in self.entries]
+            self._all_leaves = [t for t in self._leaf + self._leaf_o if t is not None]
+            self._last_ptrs = [0] * n
+            # no companions at all (kernels stored OIHW, dense models): what quantize_all() hands to the layers never changes
+            self._static_pre = self._static_outs = None
+            if not self._oihw_idx and all(lf is not None for lf in self._leaf):
+                self._static_outs = list(self._leaf)
+                self._static_pre = [(layer.__dict__, (None if ik is None else self._leaf[ik], None if ib is None else self._leaf[ib], None))
+                                    for layer, ik, ib in self._layer_slots]
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -168,13 +176,14 @@ class FakeQuantBatch:
     def _quantize_all_leaves(self):
         _hip.check(_hip.load().lq_batch_forward(self._handle, _hip.stream_ptr(self.device)), "lq_batch_forward")
         self._awaiting_finish = True
-        outs = []
-        for lf, lo in zip(self._leaf, self._leaf_o):
-            if lf is not None:
-                lf.grad = None
-            if lo is not None:
-                lo.grad = None
-            outs.append(lf if lf is not None else lo.permute(2, 3, 1, 0))      # the HWIO-shaped view of a companion-only kernel
+        for lf in self._all_leaves:
+            lf.grad = None
+        if self._static_pre is not None:                   # every tensor has its own HWIO-shaped leaf: the hand-outs never change
+            for d, pre in self._static_pre:
+                d["_q_pre"] = pre
+            return self._static_outs
+        outs = [lf if lf is not None else lo.permute(2, 3, 1, 0)      # the HWIO-shaped view of a companion-only kernel
+                for lf, lo in zip(self._leaf, self._leaf_o)]
         for layer, ik, ib in self._layer_slots:
             layer.__dict__["_q_pre"] = (None if ik is None else outs[ik], None if ib is None else outs[ib],
                                         self._leaf_o[ik] if ik is not None else None)
@@ -190,9 +199,12 @@ class FakeQuantBatch:
             # a second call would add dP to the parameters' gradients (bucket views) once more
             raise RuntimeError("finish_backward() without a quantize_all() since the last call: one backward pass per forward")
         self._awaiting_finish = False
-        dys = [None if lf is None else lf.grad for lf in self._leaf] + [self._leaf_o[i].grad for i in self._oihw_idx]
-        dps = self._backward_core(dys)
-        alias_p, add_to, add_from = [], [], []
+        if self._static_pre is not None and not self.defer_scale_grads:
+            dps = self._leaf_grads_core()
+        else:
+            dys = [None if lf is None else lf.grad for lf in self._leaf] + [self._leaf_o[i].grad for i in self._oihw_idx]
+            dps = self._backward_core(dys)
+        add_to, add_from = [], []
         for e, dp in zip(self.entries, dps):
             p = e.param
             if p.grad is None:
@@ -202,6 +214,37 @@ class FakeQuantBatch:
                 add_from.append(dp)
         if add_to:
             torch._foreach_add_(add_to, add_from)          # one fused launch for all of them
+
+    def _leaf_grads_core(self):
+        """The backward of every tensor when the upstream gradients are the leaves' own ``.grad`` (no companions): autograd's
+        AccumulateGrad has already made them float32 tensors of the leaf's shape and strides on the leaf's device (its layout
+        contract; assignment to ``.grad`` checks shape, dtype and device too), so of the per-tensor checks of ``_backward_core`` only
+        the element order is looked at; the pointer table is rewritten only where an address changed (the caching allocator hands a steady-state step the same blocks again)."""
+        ptrs, last, entries = self._ptrs, self._last_ptrs, self.entries
+        dps = []
+        for i, lf in enumerate(self._leaf):
+            d = lf.grad
+            if d is None:                                  # nothing consumed this tensor: dP = 0
+                d = torch.zeros_like(entries[i].param.data)
+            elif d.stride() != entries[i].pstride:         # a hand-assigned gradient in another element order (autograd's own obey the leaf's)
+                d = _hip.require_device_f32(d, "dy", like=entries[i].param.data)
+            a = d.data_ptr()
+            if a != last[i]:
+                ptrs[i] = a
+                last[i] = a
+            dps.append(d)
+        ext = self._external_grads
+        for e in self.entries:
+            if e.nq:
+                g = e.nested.scale
+                if g.grad is not None and not ext:
+                    raise RuntimeError("FakeQuantBatch: scale gradients must be None before backward "
+                                       "(gradient accumulation over several backward passes is not supported in batched mode)")
+        self._scale_grad_call(False)
+        for e in self.entries:
+            if e.nq:
+                e.nested.scale.grad = e.ds                 # written in place by the kernel: no accumulate launch
+        return dps
 
     def _scale_grad_call(self, oihw: bool):
         """lq_batch_scale_grad(_oihw), or -- a fused optimizer attached -- lq_batch_scale_grad_step: same launches, the finalize
