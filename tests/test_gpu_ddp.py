@@ -87,6 +87,67 @@ def test_two_rank_graphed_step_equals_eager(tmp_path, mode):
         assert torch.equal(runs["graph"][0][k], runs["eager"][0][k]), f"graphed != eager at {k} (mode {mode})"
 
 
+def _hold_worker(rank, world, port, overlap, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    import learned_quantization_amd as lq
+    from learned_quantization_amd.ddp import DataParallel
+    lq.reset_layer_names()
+    model = lq.build_model("imagenette", mode="nq", value=1e-11, seed=42, orientation="channelwise", device=dev)
+    layers = lq.custom_layers_of(model)
+    # exact mode B (scales stay outside the bucket) with the regularisers INSIDE the differentiated objective: the hooks of the
+    # regularised kernels and biases fire during backward, and a sub-bucket can consist of nothing but such parameters
+    dp = DataParallel(model, mode="B", bucket_mb=1e-3, overlap=overlap)      # ~ one sub-bucket per parameter: the big kernels are alone in theirs
+    batch = lq.FakeQuantBatch(model, hwio_out=False, autograd=False)
+    dp.attach_batch(batch)
+    assert len(dp._ranges) > 8 and dp._hold
+    if os.environ.get("LQ_TEST_MUTATE_NO_HOLD") == "1":               # mutation check of this test itself (tools/r04_job14.sh): must FAIL
+        dp._hold = set()
+    g = torch.Generator().manual_seed(100 + rank)                      # every rank its own upstream gradients
+    dp.zero_grad()
+    batch.quantize_all()
+    total = None
+    for l in layers:
+        w, qb = l.quantized_parameters()
+        for o in (w, qb):
+            if o is not None:
+                t = (o * (torch.randn(tuple(o.shape), generator=g) * 1e-3).to(dev)).sum()
+                total = t if total is None else total + t
+        if l.regularizer is not None:
+            total = total + l.regularization_loss()
+    total.backward()
+    batch.finish_backward()
+    dp.exchange()
+    torch.cuda.synchronize()
+    torch.save({n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None and not getattr(p, "lq_is_scale", False)},
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_regularised_kernels_are_exchanged_after_finish_backward(tmp_path):
+    """Leaf mode (FakeQuantBatch(autograd=False)): dP reaches the quantised parameters in finish_backward(), after loss.backward() has
+    returned -- but the hook of an l2-regularised kernel fires during backward, for the regulariser's gradient alone.  A sub-bucket
+    that holds such a kernel must not be exchanged from that hook (DataParallel.attach_batch: _hold).  Two ranks with DIFFERENT
+    upstream gradients on the ResNet-18-like net, exact mode B with the regularisers inside the objective, tiny sub-buckets: the
+    overlapping exchange must give the averaged gradients of the exchange after backward, bit for bit, on both ranks.  (A one-rank
+    group cannot see this: its all-reduce is the identity.  Checked once with the hold removed, LQ_TEST_MUTATE_NO_HOLD=1: fails.)"""
+    res = {}
+    for overlap in (False, True):
+        d = tmp_path / str(overlap)
+        d.mkdir()
+        mp.spawn(_hold_worker, args=(2, _free_port(), overlap, str(d)), nprocs=2, join=True)
+        res[overlap] = (torch.load(d / "r0.pt"), torch.load(d / "r1.pt"))
+    assert len(res[True][0]) > 40
+    for k in res[True][0]:
+        assert torch.equal(res[True][0][k], res[True][1][k]), f"ranks hold different gradients for {k}: a sub-bucket was exchanged before dP arrived"
+        assert torch.equal(res[True][0][k], res[False][0][k]), f"overlapping exchange != exchange after backward at {k}"
+
+
 def _run_script(args, timeout=600):
     import subprocess
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
