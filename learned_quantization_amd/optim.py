@@ -154,15 +154,20 @@ class KerasAdam(torch.optim.Optimizer):
         else:
             self._step += 1
         keep = []
+        f32 = torch.float32
         for group, chunk, handle, gptrs, ptrs in self._sets:
             for i, p in enumerate(chunk):
-                if p.data_ptr() != ptrs[i]:
+                d = p.data
+                if d.data_ptr() != ptrs[i]:
                     raise RuntimeError("a parameter was re-allocated after the optimizer was built; create a new KerasAdam")
                 g = p.grad
                 if g is None:
                     gptrs[i] = None
                 else:
-                    g = _hip.require_device_f32(g, "gradient", like=p.data)
+                    # this loop runs every eager step for every parameter: the cheap comparisons first (autograd's own gradients
+                    # pass them), the full checks and a relayout only where one fails
+                    if g.dtype is not f32 or g.shape != d.shape or g.stride() != d.stride() or g.device != d.device:
+                        g = _hip.require_device_f32(g, "gradient", like=d)
                     keep.append(g)
                     gptrs[i] = g.data_ptr()
             b1, b2 = group["betas"]
