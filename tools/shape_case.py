@@ -13,6 +13,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import learned_quantization_amd as lq  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: E402,F401  (LQ_HIP_LIB -> _hip.use_library)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("outer", type=int)
